@@ -1,0 +1,294 @@
+/*
+ * mirt.h — C ABI of the MI355X-native per-pixel sphere ray tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of linuxing3/weekend-raytracer-wgpu:
+ * the body of `Layer::set_data` (reference src/raytracer/layer.rs:264-282) and everything it
+ * calls.  A Rust `Layer` keeps its method surface and replaces the pixel loop with one call
+ * into this library (binding shown in INTEGRATION.md).  All structs below are byte-identical
+ * to the reference's `#[repr(C)] + bytemuck::Pod` types, so a Rust `&[T]` can be passed as
+ * `(ptr, len)` with no marshalling.
+ *
+ * Conventions
+ *   - every entry point returns 0 (MIRT_OK) or a negative MirtStatus; nothing unwinds or
+ *     aborts across the ABI; mirt_last_error() returns a thread-local message.
+ *   - the caller owns every input pointer for the duration of the call only; the library
+ *     never retains caller pointers.  Output buffers are caller-allocated.
+ *   - images are row-major, top row first, RGBA8 (A = 255): the format the reference's
+ *     consumer `Layer::register_texture` uploads (layer.rs:150-176, `to_rgba8`).
+ *   - there is NO CPU fallback behind these symbols: without a HIP device every render call
+ *     fails with MIRT_ERR_NO_DEVICE.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_VERSION_MAJOR 0
+#define MIRT_VERSION_MINOR 1
+#define MIRT_VERSION_PATCH 0
+
+/* ------------------------------------------------------------------------------------------
+ * Wire structs (reference file:line of the Rust type each one mirrors)
+ * ---------------------------------------------------------------------------------------- */
+
+/* `pub struct Sphere(glm::Vec4, f32, u32, [u32; 2])` — src/raytracer/mod.rs:418-431. 32 B. */
+typedef struct MirtSphere {
+    float    center[4];     /* xyz + w(=0), `glm::vec3_to_vec4(&center)` mod.rs:429 */
+    float    radius;
+    uint32_t material_idx;
+    uint32_t _pad[2];
+} MirtSphere;
+
+/* `pub struct TextureDescriptor { width, height, offset }` — mod.rs:869-876. 12 B.
+ * `offset` indexes the flat texel table in units of texels ([f32;3]).
+ * The "empty" descriptor is {0, 0, 0xffffffff} (mod.rs:878-886). */
+typedef struct MirtTextureDescriptor {
+    uint32_t width;
+    uint32_t height;
+    uint32_t offset;
+} MirtTextureDescriptor;
+
+/* `struct GpuMaterial { id, desc1, desc2, x }` — mod.rs:757-765. 32 B.
+ * id: 0 lambertian, 1 metal, 2 dielectric, 3 checkerboard (mod.rs:768-813).
+ * x:  fuzz (metal) or refraction index (dielectric). */
+typedef struct MirtMaterial {
+    uint32_t              id;
+    MirtTextureDescriptor desc1;
+    MirtTextureDescriptor desc2;
+    float                 x;
+} MirtMaterial;
+
+/* `pub struct GpuCamera` — mod.rs:681-697. 96 B. Produced on the host by
+ * `GpuCamera::new` (mod.rs:700-741) == mirt_camera_new() below. */
+typedef struct MirtGpuCamera {
+    float eye[3];               float _padding1;
+    float horizontal[3];        float _padding2;
+    float vertical[3];          float _padding3;
+    float u[3];                 float _padding4;
+    float v[3];                 float lens_radius;
+    float lower_left_corner[3]; float _padding5;
+} MirtGpuCamera;
+
+/* `struct GpuSkyState` — mod.rs:888-896. 144 B. Opaque Hosek-Wilkie state produced by the
+ * hw-skymodel crate on the Rust side (mod.rs:567-595); consumed by raytracer.wgsl:316-343. */
+typedef struct MirtSkyState {
+    float    params[27];
+    float    radiances[3];
+    uint32_t _padding[2];
+    float    sun_direction[4];
+} MirtSkyState;
+
+/* `pub struct Camera { eye_pos, eye_dir, up, vfov: Angle, aperture, focus_distance }` —
+ * mod.rs:489-499 (Angle is a newtype over f32 radians, angle.rs:1-4). 48 B. */
+typedef struct MirtCamera {
+    float eye_pos[3];
+    float eye_dir[3];
+    float up[3];
+    float vfov_radians;
+    float aperture;
+    float focus_distance;
+} MirtCamera;
+
+/* `pub struct SamplingParams` — mod.rs:597-603. 12 B. */
+typedef struct MirtSamplingParams {
+    uint32_t max_samples_per_pixel;
+    uint32_t num_samples_per_pixel;
+    uint32_t num_bounces;
+} MirtSamplingParams;
+
+/* The state `Layer` holds when `set_data` runs (layer.rs:37-46): camera, world (gathered from
+ * `Vec<Box<Sphere>>` into one contiguous slice), material_data, global_texture_data. */
+typedef struct MirtScene {
+    const MirtGpuCamera* camera;
+    const MirtSphere*    spheres;
+    uint32_t             n_spheres;
+    const MirtMaterial*  materials;
+    uint32_t             n_materials;
+    const float*         texels;      /* [n_texels][3] f32, `Vec<[f32;3]>` layer.rs:44 */
+    uint64_t             n_texels;
+    const MirtSkyState*  sky;         /* nullable; required only with MIRT_FLAG_SKY_HOSEK */
+} MirtScene;
+
+/* Render modes. */
+enum {
+    /* `layer.rs` semantics, bit-faithful, every quirk preserved. */
+    MIRT_MODE_PARITY = 0,
+    /* Full path tracer with the behaviours of raytracer.wgsl:105-521. */
+    MIRT_MODE_PT = 1
+};
+
+/* Flags (MIRT_MODE_PT only; ignored in parity mode). */
+enum {
+    MIRT_FLAG_SKY_HOSEK      = 1u << 0, /* sky = Hosek-Wilkie blob (wgsl:154-166,316-343); default: RTIOW gradient */
+    MIRT_FLAG_NO_TONEMAP     = 1u << 1, /* skip uncharted2 (wgsl:83-103) */
+    MIRT_FLAG_NO_SRGB        = 1u << 2, /* skip the sRGB OETF the Bgra8UnormSrgb surface applies (main.rs:465) */
+    MIRT_FLAG_COUNT_WORK     = 1u << 3  /* run the counting build of the kernel: fills MirtStats work counters */
+};
+
+/* What one render call computes.  The image is `width x height`; this call renders the rows
+ * selected by (row_begin,row_end) and the tile interleave, into a COMPACT buffer of
+ * mirt_params_out_rows() rows.  With tile_rows == 0 (or n_parts <= 1) the rows are the
+ * contiguous band [row_begin,row_end).  With n_parts > 1 the band is cut into tiles of
+ * `tile_rows` rows and this call renders tiles t with t % n_parts == part, in order — the
+ * partition used to balance the 8 GPUs of a node. */
+typedef struct MirtParams {
+    uint32_t width;        /* `vp_size[0] as u32` layer.rs:270-275 */
+    uint32_t height;
+    uint32_t spp;          /* `sampling.num_samples_per_pixel` layer.rs:316 */
+    uint32_t num_bounces;  /* PT mode; SamplingParams.num_bounces mod.rs:602 */
+    uint32_t mode;         /* MIRT_MODE_* */
+    uint32_t flags;        /* MIRT_FLAG_* */
+    uint64_t seed;         /* PT mode RNG seed; 0 reproduces the WGSL stream (wgsl:498-502) */
+    uint32_t row_begin;    /* band; row_end == 0 means `height` */
+    uint32_t row_end;
+    uint32_t tile_rows;    /* 0 = no interleave */
+    uint32_t n_parts;
+    uint32_t part;
+    uint32_t sample_begin; /* PT: first sample index (progressive accumulation); normally 0 */
+} MirtParams;
+
+/* Work counters of the last render on a context (rocprof-independent).  The ray/test/scatter
+ * counters are filled only when MIRT_FLAG_COUNT_WORK was set. */
+typedef struct MirtStats {
+    double   kernel_ms;        /* hipEvent time of the render kernel(s) of the last call */
+    uint64_t samples;          /* pixels x spp rendered by the last call */
+    uint64_t rays;             /* rays traced (primary + scattered) */
+    uint64_t sphere_tests;     /* ray-sphere discriminant evaluations */
+    uint64_t roots;            /* quadratic roots evaluated */
+    uint64_t hits;             /* hit records built */
+    uint64_t scatter[5];       /* lambertian, metal, dielectric, checkerboard, missing-material */
+    uint64_t sky_misses;       /* rays that left the scene */
+    uint64_t lane_iterations;  /* PT: active lanes summed over bounce-loop iterations */
+    uint64_t wave_iterations;  /* PT: bounce-loop iterations summed over waves (x64 = lane slots) */
+} MirtStats;
+
+typedef enum MirtStatus {
+    MIRT_OK                      =  0,
+    /* mirrors RenderParamsValidationError, mod.rs:396-411 / RenderParams::validate mod.rs:450-484 */
+    MIRT_ERR_MAX_SAMPLES_MULTIPLE = -1, /* MaxSampleCountNotMultiple */
+    MIRT_ERR_VIEWPORT_SIZE        = -2, /* ViewportSize */
+    MIRT_ERR_VFOV_RANGE           = -3, /* VfovOutOfRange */
+    MIRT_ERR_APERTURE_RANGE       = -4, /* ApertureOutOfRange */
+    MIRT_ERR_FOCUS_DISTANCE       = -5, /* FocusDistanceOutOfRange */
+    MIRT_ERR_SKY                  = -6, /* HwSkyModelValidationError / sky blob missing */
+    /* library-level */
+    MIRT_ERR_NULL_POINTER         = -10,
+    MIRT_ERR_SPP_ZERO             = -11,
+    MIRT_ERR_BAD_MODE             = -12,
+    MIRT_ERR_BAD_ROWS             = -13,
+    MIRT_ERR_MATERIAL_INDEX       = -14, /* sphere.material_idx >= n_materials, or parity mode with n_materials < 3 (layer.rs:345-349 reads material_data[2]) */
+    MIRT_ERR_TEXEL_RANGE          = -15, /* a descriptor reaches past n_texels */
+    MIRT_ERR_OUT_BUFFER           = -16, /* out_len too small */
+    MIRT_ERR_NO_SCENE             = -17,
+    MIRT_ERR_SCENE_TOO_LARGE      = -18, /* spheres+materials do not fit the LDS budget */
+    MIRT_ERR_NO_DEVICE            = -20,
+    MIRT_ERR_HIP                  = -21,
+    MIRT_ERR_ALLOC                = -22
+} MirtStatus;
+
+typedef struct MirtContext MirtContext; /* opaque: one per device; owns all device memory */
+
+/* ------------------------------------------------------------------------------------------
+ * Entry points
+ * ---------------------------------------------------------------------------------------- */
+
+/* Packed version (major<<16 | minor<<8 | patch). */
+uint32_t    mirt_version(void);
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* mirt_last_error(void);
+/* Static name of a status code. */
+const char* mirt_status_string(int status);
+
+/* `RenderParams::validate` (mod.rs:450-484) over the fields that reach this path. */
+int mirt_validate_render_params(const MirtCamera* camera, const MirtSamplingParams* sampling,
+                                uint32_t viewport_w, uint32_t viewport_h);
+
+/* `GpuCamera::new(&camera, viewport_size)` (mod.rs:700-741).  Host-side set-up arithmetic in
+ * f32 exactly as the reference does it; runs once per image, not part of the hot loop. */
+int mirt_camera_new(const MirtCamera* camera, uint32_t viewport_w, uint32_t viewport_h,
+                    MirtGpuCamera* out);
+
+/* `camera_orientation` + `FlyCameraController::renderer_camera` (fly_camera.rs:52-64,227-241):
+ * pose (position, yaw, pitch in radians) -> Camera. */
+int mirt_camera_from_fly_pose(const float position[3], float yaw_radians, float pitch_radians,
+                              float vfov_degrees, float aperture, float focus_distance,
+                              MirtCamera* out);
+
+/* `Angle::degrees(d).as_radians()` (angle.rs:8-12): d * PI / 180 in f32. */
+float mirt_degrees_to_radians(float degrees);
+/* `Angle::as_degrees` (angle.rs:20-22): r * 180 / PI in f32. */
+float mirt_radians_to_degrees(float radians);
+
+/* Number of rows a render call with these params writes (0 on invalid params). */
+uint32_t mirt_params_out_rows(const MirtParams* params);
+/* Absolute image row of compact output row `i` (UINT32_MAX if out of range). */
+uint32_t mirt_params_out_row_index(const MirtParams* params, uint32_t i);
+
+/* Create / destroy a context on HIP device `device` (ordinal as seen by this process). */
+int  mirt_ctx_create(int device, MirtContext** out);
+void mirt_ctx_destroy(MirtContext* ctx);
+
+/* Validate and upload the scene into device memory owned by the context (what
+ * `Layer::new` + `set_global_data` leave in `self`, layer.rs:49-148).  The scene stays
+ * resident across render calls until replaced. */
+int mirt_ctx_set_scene(MirtContext* ctx, const MirtScene* scene);
+/* Replace only the camera (`Layer::update_camera`, layer.rs:188-193). */
+int mirt_ctx_set_camera(MirtContext* ctx, const MirtGpuCamera* camera);
+
+/* Render into HOST memory: kernel + D2H copy, blocking.  `out_rgba8` receives
+ * mirt_params_out_rows() * width * 4 bytes.  This is the `set_data` replacement. */
+int mirt_ctx_render(MirtContext* ctx, const MirtParams* params, uint8_t* out_rgba8, size_t out_len);
+
+/* Render into DEVICE memory `d_out_rgba8` (same layout) asynchronously on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the context's own stream).  No host sync: the
+ * caller orders later work on the same stream (RCCL gather, D2H).  Used by bench.py and
+ * the multi-GPU path so the framebuffer never leaves HBM before the collective. */
+int mirt_ctx_render_device(MirtContext* ctx, const MirtParams* params, void* d_out_rgba8,
+                           size_t out_len, void* hip_stream);
+
+/* Block until everything the context queued has finished. */
+int mirt_ctx_synchronize(MirtContext* ctx);
+/* Stats of the last completed render call (synchronises the context first). */
+int mirt_ctx_get_stats(MirtContext* ctx, MirtStats* out);
+
+/* One-shot convenience: create context on `device`, set scene, render to host, destroy.
+ * Signature a Rust `set_data` binds when it does not keep a context. */
+int mirt_render(const MirtScene* scene, const MirtParams* params, int device,
+                uint8_t* out_rgba8, size_t out_len);
+
+/* RGBA8 -> RGB8 view for `Layer::imgbuf()` (layer.rs:182-186; `ImageBuffer<Rgb<u8>>`). Host-side
+ * repack of n_pixels pixels. */
+int mirt_rgba8_to_rgb8(const uint8_t* rgba, size_t n_pixels, uint8_t* rgb);
+
+/* Reassemble a full image from the `n_parts` compact buffers produced with the tile
+ * interleave (root side of the multi-GPU gather).  `parts` holds n_parts buffers
+ * back-to-back, each padded to `part_stride` bytes.  Device-side: both pointers are
+ * device memory; runs on `hip_stream`. */
+int mirt_ctx_deinterleave_device(MirtContext* ctx, const MirtParams* params, const void* d_parts,
+                                 size_t part_stride, void* d_out_rgba8, size_t out_len,
+                                 void* hip_stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(MirtSphere) == 32, "Sphere is 32 B (mod.rs:418-421)");
+static_assert(sizeof(MirtTextureDescriptor) == 12, "TextureDescriptor is 12 B (mod.rs:869-876)");
+static_assert(sizeof(MirtMaterial) == 32, "GpuMaterial is 32 B (mod.rs:757-765)");
+static_assert(sizeof(MirtGpuCamera) == 96, "GpuCamera is 96 B (mod.rs:681-697)");
+static_assert(sizeof(MirtSkyState) == 144, "GpuSkyState is 144 B (mod.rs:888-896)");
+static_assert(sizeof(MirtCamera) == 48, "Camera is 12 f32 (mod.rs:489-499)");
+#else
+_Static_assert(sizeof(MirtSphere) == 32, "Sphere is 32 B (mod.rs:418-421)");
+_Static_assert(sizeof(MirtTextureDescriptor) == 12, "TextureDescriptor is 12 B (mod.rs:869-876)");
+_Static_assert(sizeof(MirtMaterial) == 32, "GpuMaterial is 32 B (mod.rs:757-765)");
+_Static_assert(sizeof(MirtGpuCamera) == 96, "GpuCamera is 96 B (mod.rs:681-697)");
+_Static_assert(sizeof(MirtSkyState) == 144, "GpuSkyState is 144 B (mod.rs:888-896)");
+_Static_assert(sizeof(MirtCamera) == 48, "Camera is 12 f32 (mod.rs:489-499)");
+#endif
+
+#endif /* MIRT_H */

@@ -1,0 +1,523 @@
+// mirt_api.hip — the C ABI of include/mirt.h: host-side validation, scene residency, kernel
+// launches and timing.  No CPU rendering path exists here: without a HIP device every render
+// entry point fails with MIRT_ERR_NO_DEVICE.
+//
+// Host arithmetic that the reference also does on the host (GpuCamera::new, camera_orientation,
+// Angle, RenderParams::validate) is restated here in f32 without contraction
+// (-ffp-contract=off applies to host code too).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "mirt_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(MIRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- MirtParams row selection ----
+bool rows_valid(const MirtParams* p, uint32_t* rb, uint32_t* re)
+{
+    const uint32_t b = p->row_begin, e = p->row_end == 0 ? p->height : p->row_end;
+    if (b >= e || e > p->height) return false;
+    if (p->tile_rows != 0 && p->n_parts > 1 && p->part >= p->n_parts) return false;
+    *rb = b;
+    *re = e;
+    return true;
+}
+
+uint32_t out_rows(const MirtParams* p)
+{
+    uint32_t rb, re;
+    if (!p || p->width == 0 || p->height == 0 || !rows_valid(p, &rb, &re)) return 0;
+    const uint32_t band = re - rb;
+    if (p->tile_rows == 0 || p->n_parts <= 1) return band;
+    const uint32_t tr = p->tile_rows;
+    const uint32_t tiles = (band + tr - 1) / tr;
+    if (tiles <= p->part) return 0;
+    const uint32_t owned = (tiles - p->part + p->n_parts - 1) / p->n_parts;
+    uint32_t rows = owned * tr;
+    if ((tiles - 1) % p->n_parts == p->part) rows -= tiles * tr - band;
+    return rows;
+}
+
+bool desc_ok(const MirtTextureDescriptor& d, uint64_t n_texels)
+{
+    if (d.width == 0 || d.height == 0) return false;
+    return (uint64_t)d.offset + (uint64_t)d.width * (uint64_t)d.height <= n_texels;
+}
+
+// jenkinsHash (raytracer.wgsl:513-521) — used to fold the 64-bit seed into the stream key
+uint32_t jenkins_hash(uint32_t x)
+{
+    x += x << 10; x ^= x >> 6; x += x << 3; x ^= x >> 11; x += x << 15;
+    return x;
+}
+
+constexpr float kRustPi = 3.14159265358979323846f;   // std::f32::consts::PI
+
+struct V3 { float x, y, z; };
+// nalgebra 3-vector arithmetic (no fusion): dot = (a0*b0 + a1*b1) + a2*b2; normalize = v / sqrt(dot)
+float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+V3 normalize3(V3 a) { const float n = std::sqrt(dot3(a, a)); return V3{ a.x / n, a.y / n, a.z / n }; }
+V3 cross3(V3 a, V3 b) { return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+V3 scale3(float s, V3 a) { return V3{ s * a.x, s * a.y, s * a.z }; }
+V3 add3(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+V3 sub3(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+
+template <typename T>
+int ensure_capacity(T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap && *ptr) return MIRT_OK;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    const size_t bytes = (need ? need : 1) * sizeof(T);
+    if (hipMalloc(ptr, bytes) != hipSuccess) return fail(MIRT_ERR_ALLOC, "hipMalloc(%zu bytes) failed", bytes);
+    *cap = need ? need : 1;
+    return MIRT_OK;
+}
+
+}  // namespace
+
+struct MirtContext {
+    int         device = -1;
+    int         cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev_begin = nullptr, ev_end = nullptr;
+    bool        timing_pending = false;
+
+    // resident scene
+    bool     have_scene = false;
+    uint32_t n_spheres = 0, n_mats = 0;
+    uint64_t n_texels = 0;
+    bool     have_sky = false;
+    bool     mats_ok_for_pt = false;      // validation results cached at set_scene
+    int      pt_scene_status = MIRT_OK;
+    int      parity_scene_status = MIRT_OK;
+    MirtGpuCamera*        d_cam = nullptr;
+    mirt::PreparedSphere* d_spheres = nullptr;
+    MirtMaterial*         d_mats = nullptr;
+    float*                d_texels = nullptr;
+    MirtSkyState*         d_sky = nullptr;
+    size_t cap_spheres = 0, cap_mats = 0, cap_texels = 0;
+
+    // per-launch state
+    unsigned long long* d_counters = nullptr;
+    uint32_t*           d_work_counter = nullptr;
+    uint32_t*           d_out = nullptr;     // scratch framebuffer for host-output renders
+    size_t              cap_out = 0;
+
+    MirtStats stats{};
+    bool      stats_counted = false;
+};
+
+extern "C" {
+
+uint32_t mirt_version(void) { return (MIRT_VERSION_MAJOR << 16) | (MIRT_VERSION_MINOR << 8) | MIRT_VERSION_PATCH; }
+
+const char* mirt_last_error(void) { return g_err; }
+
+const char* mirt_status_string(int status)
+{
+    switch (status) {
+    case MIRT_OK: return "MIRT_OK";
+    case MIRT_ERR_MAX_SAMPLES_MULTIPLE: return "MIRT_ERR_MAX_SAMPLES_MULTIPLE";
+    case MIRT_ERR_VIEWPORT_SIZE: return "MIRT_ERR_VIEWPORT_SIZE";
+    case MIRT_ERR_VFOV_RANGE: return "MIRT_ERR_VFOV_RANGE";
+    case MIRT_ERR_APERTURE_RANGE: return "MIRT_ERR_APERTURE_RANGE";
+    case MIRT_ERR_FOCUS_DISTANCE: return "MIRT_ERR_FOCUS_DISTANCE";
+    case MIRT_ERR_SKY: return "MIRT_ERR_SKY";
+    case MIRT_ERR_NULL_POINTER: return "MIRT_ERR_NULL_POINTER";
+    case MIRT_ERR_SPP_ZERO: return "MIRT_ERR_SPP_ZERO";
+    case MIRT_ERR_BAD_MODE: return "MIRT_ERR_BAD_MODE";
+    case MIRT_ERR_BAD_ROWS: return "MIRT_ERR_BAD_ROWS";
+    case MIRT_ERR_MATERIAL_INDEX: return "MIRT_ERR_MATERIAL_INDEX";
+    case MIRT_ERR_TEXEL_RANGE: return "MIRT_ERR_TEXEL_RANGE";
+    case MIRT_ERR_OUT_BUFFER: return "MIRT_ERR_OUT_BUFFER";
+    case MIRT_ERR_NO_SCENE: return "MIRT_ERR_NO_SCENE";
+    case MIRT_ERR_SCENE_TOO_LARGE: return "MIRT_ERR_SCENE_TOO_LARGE";
+    case MIRT_ERR_NO_DEVICE: return "MIRT_ERR_NO_DEVICE";
+    case MIRT_ERR_HIP: return "MIRT_ERR_HIP";
+    case MIRT_ERR_ALLOC: return "MIRT_ERR_ALLOC";
+    default: return "MIRT_ERR_UNKNOWN";
+    }
+}
+
+// Angle::degrees / as_degrees (reference src/raytracer/angle.rs:8-22)
+float mirt_degrees_to_radians(float degrees) { return degrees * kRustPi / 180.0f; }
+float mirt_radians_to_degrees(float radians) { return radians * 180.0f / kRustPi; }
+
+// RenderParams::validate (reference src/raytracer/mod.rs:450-484), same order of checks
+int mirt_validate_render_params(const MirtCamera* camera, const MirtSamplingParams* sampling, uint32_t w, uint32_t h)
+{
+    if (!camera || !sampling) return fail(MIRT_ERR_NULL_POINTER, "camera/sampling is null");
+    if (sampling->num_samples_per_pixel == 0)
+        return fail(MIRT_ERR_SPP_ZERO, "num_samples_per_pixel is zero");
+    if (sampling->max_samples_per_pixel % sampling->num_samples_per_pixel != 0)
+        return fail(MIRT_ERR_MAX_SAMPLES_MULTIPLE, "max_samples_per_pixel (%u) is not a multiple of num_samples_per_pixel (%u)",
+                    sampling->max_samples_per_pixel, sampling->num_samples_per_pixel);
+    if (w == 0 || h == 0) return fail(MIRT_ERR_VIEWPORT_SIZE, "viewport_size elements cannot be zero: (%u, %u)", w, h);
+    const float lo = mirt_degrees_to_radians(0.0f), hi = mirt_degrees_to_radians(90.0f);
+    if (!(camera->vfov_radians >= lo && camera->vfov_radians <= hi))
+        return fail(MIRT_ERR_VFOV_RANGE, "vfov must be between 0..=90 degrees");
+    if (!(camera->aperture >= 0.0f && camera->aperture <= 1.0f))
+        return fail(MIRT_ERR_APERTURE_RANGE, "aperture must be between 0..=1");
+    if (camera->focus_distance < 0.0f)
+        return fail(MIRT_ERR_FOCUS_DISTANCE, "focus_distance must be greater than zero");
+    return MIRT_OK;
+}
+
+// GpuCamera::new (reference src/raytracer/mod.rs:700-741)
+int mirt_camera_new(const MirtCamera* camera, uint32_t vw, uint32_t vh, MirtGpuCamera* out)
+{
+    if (!camera || !out) return fail(MIRT_ERR_NULL_POINTER, "camera/out is null");
+    if (vw == 0 || vh == 0) return fail(MIRT_ERR_VIEWPORT_SIZE, "viewport_size elements cannot be zero: (%u, %u)", vw, vh);
+    const float lens_radius = 0.5f * camera->aperture;
+    const float aspect = (float)vw / (float)vh;
+    const float half_height = camera->focus_distance * std::tan(0.5f * camera->vfov_radians);
+    const float half_width = aspect * half_height;
+    const V3 eye{ camera->eye_pos[0], camera->eye_pos[1], camera->eye_pos[2] };
+    const V3 w = normalize3(V3{ camera->eye_dir[0], camera->eye_dir[1], camera->eye_dir[2] });
+    const V3 v = normalize3(V3{ camera->up[0], camera->up[1], camera->up[2] });
+    const V3 u = cross3(w, v);
+    const V3 llc = sub3(sub3(add3(eye, scale3(camera->focus_distance, w)), scale3(half_width, u)), scale3(half_height, v));
+    const V3 horizontal = scale3(2.0f * half_width, u);
+    const V3 vertical = scale3(2.0f * half_height, v);
+    std::memset(out, 0, sizeof *out);
+    out->eye[0] = eye.x; out->eye[1] = eye.y; out->eye[2] = eye.z;
+    out->horizontal[0] = horizontal.x; out->horizontal[1] = horizontal.y; out->horizontal[2] = horizontal.z;
+    out->vertical[0] = vertical.x; out->vertical[1] = vertical.y; out->vertical[2] = vertical.z;
+    out->u[0] = u.x; out->u[1] = u.y; out->u[2] = u.z;
+    out->v[0] = v.x; out->v[1] = v.y; out->v[2] = v.z;
+    out->lens_radius = lens_radius;
+    out->lower_left_corner[0] = llc.x; out->lower_left_corner[1] = llc.y; out->lower_left_corner[2] = llc.z;
+    return MIRT_OK;
+}
+
+// camera_orientation + FlyCameraController::renderer_camera (reference src/fly_camera.rs:52-64, 227-241)
+int mirt_camera_from_fly_pose(const float position[3], float yaw, float pitch, float vfov_degrees, float aperture,
+                              float focus_distance, MirtCamera* out)
+{
+    if (!position || !out) return fail(MIRT_ERR_NULL_POINTER, "position/out is null");
+    const V3 forward = normalize3(V3{ std::cos(yaw) * std::cos(pitch), std::sin(pitch), std::sin(yaw) * std::cos(pitch) });
+    const V3 right = cross3(forward, V3{ 0.0f, 1.0f, 0.0f });
+    const V3 up = cross3(right, forward);
+    out->eye_pos[0] = position[0]; out->eye_pos[1] = position[1]; out->eye_pos[2] = position[2];
+    out->eye_dir[0] = forward.x; out->eye_dir[1] = forward.y; out->eye_dir[2] = forward.z;
+    out->up[0] = up.x; out->up[1] = up.y; out->up[2] = up.z;
+    out->vfov_radians = mirt_degrees_to_radians(vfov_degrees);
+    out->aperture = aperture;
+    out->focus_distance = focus_distance;
+    return MIRT_OK;
+}
+
+uint32_t mirt_params_out_rows(const MirtParams* params) { return out_rows(params); }
+
+uint32_t mirt_params_out_row_index(const MirtParams* p, uint32_t i)
+{
+    uint32_t rb, re;
+    if (!p || !rows_valid(p, &rb, &re) || i >= out_rows(p)) return UINT32_MAX;
+    if (p->tile_rows == 0 || p->n_parts <= 1) return rb + i;
+    const uint32_t t = p->part + (i / p->tile_rows) * p->n_parts;
+    return rb + t * p->tile_rows + i % p->tile_rows;
+}
+
+int mirt_ctx_create(int device, MirtContext** out)
+{
+    if (!out) return fail(MIRT_ERR_NULL_POINTER, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MIRT_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    MirtContext* c = new (std::nothrow) MirtContext();
+    if (!c) return fail(MIRT_ERR_ALLOC, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
+    if (e == hipSuccess) e = hipMalloc(&c->d_cam, sizeof(MirtGpuCamera));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters);
+    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        mirt_ctx_destroy(c);
+        return rc;
+    }
+    c->cu_count = prop.multiProcessorCount;
+    *out = c;
+    return MIRT_OK;
+}
+
+void mirt_ctx_destroy(MirtContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_texels);
+    (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
+{
+    if (!c || !s || !s->camera) return fail(MIRT_ERR_NULL_POINTER, "ctx/scene/camera is null");
+    if (s->n_spheres && !s->spheres) return fail(MIRT_ERR_NULL_POINTER, "spheres is null");
+    if (s->n_materials && !s->materials) return fail(MIRT_ERR_NULL_POINTER, "materials is null");
+    if (s->n_texels && !s->texels) return fail(MIRT_ERR_NULL_POINTER, "texels is null");
+    if (mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true) > mirt::kMaxLdsBytes)
+        return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
+                    s->n_materials, mirt::kMaxLdsBytes);
+    HIP_TRY(hipSetDevice(c->device));
+
+    // mode-specific validity is decided here once and reported by the render call that needs it
+    c->pt_scene_status = MIRT_OK;
+    for (uint32_t i = 0; i < s->n_spheres && c->pt_scene_status == MIRT_OK; ++i)
+        if (s->spheres[i].material_idx >= s->n_materials) c->pt_scene_status = MIRT_ERR_MATERIAL_INDEX;
+    for (uint32_t i = 0; i < s->n_materials && c->pt_scene_status == MIRT_OK; ++i) {
+        const MirtMaterial& m = s->materials[i];
+        if ((m.id == 0 || m.id == 1 || m.id == 3) && !desc_ok(m.desc1, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
+        if (m.id == 3 && !desc_ok(m.desc2, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
+    }
+    c->parity_scene_status = MIRT_OK;
+    if (s->n_spheres > 0) {   // layer.rs:345-349 reads material_data[2] on every primary hit
+        if (s->n_materials < 3) c->parity_scene_status = MIRT_ERR_MATERIAL_INDEX;
+        else if (!desc_ok(s->materials[2].desc1, s->n_texels)) c->parity_scene_status = MIRT_ERR_TEXEL_RANGE;
+    }
+
+    std::vector<mirt::PreparedSphere> prep(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const MirtSphere& in = s->spheres[i];
+        mirt::PreparedSphere& o = prep[i];
+        o.cx = in.center[0]; o.cy = in.center[1]; o.cz = in.center[2];
+        o.rr = in.radius * in.radius;
+        o.inv_r = 1.0f / in.radius;
+        o.radius = in.radius;
+        o.material_idx = in.material_idx;
+        o._pad = 0;
+    }
+    int rc;
+    if ((rc = ensure_capacity(&c->d_spheres, &c->cap_spheres, (size_t)s->n_spheres)) != MIRT_OK) return rc;
+    if ((rc = ensure_capacity(&c->d_mats, &c->cap_mats, (size_t)s->n_materials)) != MIRT_OK) return rc;
+    if ((rc = ensure_capacity(&c->d_texels, &c->cap_texels, (size_t)s->n_texels * 3)) != MIRT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_cam, s->camera, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
+    if (s->n_spheres) HIP_TRY(hipMemcpy(c->d_spheres, prep.data(), prep.size() * sizeof(mirt::PreparedSphere), hipMemcpyHostToDevice));
+    if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
+    if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    c->have_sky = s->sky != nullptr;
+    if (s->sky) HIP_TRY(hipMemcpy(c->d_sky, s->sky, sizeof(MirtSkyState), hipMemcpyHostToDevice));
+    c->n_spheres = s->n_spheres;
+    c->n_mats = s->n_materials;
+    c->n_texels = s->n_texels;
+    c->have_scene = true;
+    return MIRT_OK;
+}
+
+int mirt_ctx_set_camera(MirtContext* c, const MirtGpuCamera* cam)
+{
+    if (!c || !cam) return fail(MIRT_ERR_NULL_POINTER, "ctx/camera is null");
+    if (!c->have_scene) return fail(MIRT_ERR_NO_SCENE, "set_scene has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_cam, cam, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
+    return MIRT_OK;
+}
+
+static int check_params(const MirtContext* c, const MirtParams* p)
+{
+    if (!c || !p) return fail(MIRT_ERR_NULL_POINTER, "ctx/params is null");
+    if (!c->have_scene) return fail(MIRT_ERR_NO_SCENE, "set_scene has not been called");
+    if (p->width == 0 || p->height == 0)
+        return fail(MIRT_ERR_VIEWPORT_SIZE, "viewport_size elements cannot be zero: (%u, %u)", p->width, p->height);
+    if (p->spp == 0) return fail(MIRT_ERR_SPP_ZERO, "spp is zero");
+    if (p->mode != MIRT_MODE_PARITY && p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "unknown mode %u", p->mode);
+    uint32_t rb, re;
+    if (!rows_valid(p, &rb, &re)) return fail(MIRT_ERR_BAD_ROWS, "invalid row selection [%u,%u) of %u, part %u/%u", p->row_begin, p->row_end, p->height, p->part, p->n_parts);
+    if (p->mode == MIRT_MODE_PARITY) {
+        if (c->parity_scene_status != MIRT_OK)
+            return fail(c->parity_scene_status, "parity mode needs material_data[2] with a valid texture (layer.rs:345-351)");
+    } else {
+        if (c->pt_scene_status != MIRT_OK) return fail(c->pt_scene_status, "scene tables are inconsistent: %s", mirt_status_string(c->pt_scene_status));
+        if ((p->flags & MIRT_FLAG_SKY_HOSEK) && !c->have_sky) return fail(MIRT_ERR_SKY, "MIRT_FLAG_SKY_HOSEK needs scene.sky");
+    }
+    if ((uint64_t)out_rows(p) * p->width > 0xffffffffull) return fail(MIRT_ERR_BAD_ROWS, "more than 2^32 pixels in one call");
+    return MIRT_OK;
+}
+
+static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream)
+{
+    const uint32_t rows = out_rows(p);
+    const uint64_t npix = (uint64_t)rows * p->width;
+    const bool count = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_COUNT_WORK);
+    const bool hosek = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_SKY_HOSEK);
+
+    mirt::RenderArgs a{};
+    a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.texels = c->d_texels; a.sky = c->d_sky;
+    a.out = d_out; a.counters = c->d_counters; a.work_counter = c->d_work_counter;
+    a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
+    a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
+    a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
+    a.sample_begin = p->sample_begin;
+    a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
+    a.out_rows = rows;
+    a.n_strips = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
+    a.lds_bytes = (uint32_t)mirt::scene_lds_bytes(c->n_spheres, c->n_mats, hosek);
+
+    const uint32_t waves_per_block = mirt::kBlockThreads / 64;
+    uint32_t blocks = (a.n_strips + waves_per_block - 1) / waves_per_block;
+    const uint32_t resident = (uint32_t)c->cu_count * 8u;     // 2048 threads per CU / 256
+    if (blocks > resident) blocks = resident;
+    if (blocks == 0) blocks = 1;
+
+    HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), stream));
+    if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
+    HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
+    else HIP_TRY(mirt::launch_pt(a, blocks, count, stream));
+    HIP_TRY(hipEventRecord(c->ev_end, stream));
+    c->timing_pending = true;
+    c->stats_counted = count;
+    c->stats = MirtStats{};
+    c->stats.samples = npix * p->spp;
+    return MIRT_OK;
+}
+
+int mirt_ctx_render_device(MirtContext* c, const MirtParams* p, void* d_out, size_t out_len, void* hip_stream)
+{
+    int rc = check_params(c, p);
+    if (rc != MIRT_OK) return rc;
+    if (!d_out) return fail(MIRT_ERR_NULL_POINTER, "d_out_rgba8 is null");
+    const size_t need = (size_t)out_rows(p) * p->width * 4;
+    if (out_len < need) return fail(MIRT_ERR_OUT_BUFFER, "output buffer holds %zu bytes, %zu needed", out_len, need);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return launch_render(c, p, (uint32_t*)d_out, st);
+}
+
+int mirt_ctx_render(MirtContext* c, const MirtParams* p, uint8_t* out, size_t out_len)
+{
+    int rc = check_params(c, p);
+    if (rc != MIRT_OK) return rc;
+    if (!out) return fail(MIRT_ERR_NULL_POINTER, "out_rgba8 is null");
+    const size_t npix = (size_t)out_rows(p) * p->width;
+    if (out_len < npix * 4) return fail(MIRT_ERR_OUT_BUFFER, "output buffer holds %zu bytes, %zu needed", out_len, npix * 4);
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure_capacity(&c->d_out, &c->cap_out, npix)) != MIRT_OK) return rc;
+    if ((rc = launch_render(c, p, c->d_out, c->stream)) != MIRT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_ctx_synchronize(MirtContext* c)
+{
+    if (!c) return fail(MIRT_ERR_NULL_POINTER, "ctx is null");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timing_pending) HIP_TRY(hipEventSynchronize(c->ev_end));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
+{
+    if (!c || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timing_pending) {
+        HIP_TRY(hipEventSynchronize(c->ev_end));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        c->stats.kernel_ms = ms;
+        if (c->stats_counted) {
+            unsigned long long h[mirt::kNumCounters];
+            HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+            c->stats.rays = h[mirt::kCntRays];
+            c->stats.sphere_tests = h[mirt::kCntTests];
+            c->stats.roots = h[mirt::kCntRoots];
+            c->stats.hits = h[mirt::kCntHits];
+            for (int i = 0; i < 5; ++i) c->stats.scatter[i] = h[mirt::kCntScatter0 + i];
+            c->stats.sky_misses = h[mirt::kCntSky];
+            c->stats.lane_iterations = h[mirt::kCntLaneIters];
+            c->stats.wave_iterations = h[mirt::kCntWaveIters];
+        }
+        c->timing_pending = false;
+    }
+    *out = c->stats;
+    return MIRT_OK;
+}
+
+int mirt_render(const MirtScene* scene, const MirtParams* params, int device, uint8_t* out, size_t out_len)
+{
+    MirtContext* c = nullptr;
+    int rc = mirt_ctx_create(device, &c);
+    if (rc != MIRT_OK) return rc;
+    rc = mirt_ctx_set_scene(c, scene);
+    if (rc == MIRT_OK) rc = mirt_ctx_render(c, params, out, out_len);
+    mirt_ctx_destroy(c);
+    return rc;
+}
+
+int mirt_rgba8_to_rgb8(const uint8_t* rgba, size_t n_pixels, uint8_t* rgb)
+{
+    if (!rgba || !rgb) return fail(MIRT_ERR_NULL_POINTER, "rgba/rgb is null");
+    for (size_t i = 0; i < n_pixels; ++i) {
+        rgb[3 * i + 0] = rgba[4 * i + 0];
+        rgb[3 * i + 1] = rgba[4 * i + 1];
+        rgb[3 * i + 2] = rgba[4 * i + 2];
+    }
+    return MIRT_OK;
+}
+
+int mirt_ctx_deinterleave_device(MirtContext* c, const MirtParams* p, const void* d_parts, size_t part_stride,
+                                 void* d_out, size_t out_len, void* hip_stream)
+{
+    if (!c || !p || !d_parts || !d_out) return fail(MIRT_ERR_NULL_POINTER, "ctx/params/buffers is null");
+    uint32_t rb, re;
+    if (p->width == 0 || p->height == 0 || !rows_valid(p, &rb, &re)) return fail(MIRT_ERR_BAD_ROWS, "invalid row selection");
+    if (p->tile_rows == 0 || p->n_parts <= 1) return fail(MIRT_ERR_BAD_ROWS, "params describe no tile interleave");
+    const uint32_t band = re - rb;
+    if (out_len < (size_t)band * p->width * 4) return fail(MIRT_ERR_OUT_BUFFER, "output buffer too small");
+    if (part_stride % 4 != 0) return fail(MIRT_ERR_OUT_BUFFER, "part_stride must be a multiple of 4 bytes");
+    MirtParams q = *p;
+    uint32_t max_rows = 0;
+    for (uint32_t i = 0; i < p->n_parts; ++i) { q.part = i; const uint32_t r = out_rows(&q); if (r > max_rows) max_rows = r; }
+    if (part_stride < (size_t)max_rows * p->width * 4) return fail(MIRT_ERR_OUT_BUFFER, "part_stride smaller than the largest part");
+    HIP_TRY(hipSetDevice(c->device));
+    mirt::DeinterleaveArgs d{};
+    d.parts = (const uint32_t*)d_parts; d.out = (uint32_t*)d_out; d.part_stride_px = part_stride / 4;
+    d.width = p->width; d.band_rows = band; d.tile_rows = p->tile_rows; d.n_parts = p->n_parts;
+    HIP_TRY(mirt::launch_deinterleave(d, hip_stream ? (hipStream_t)hip_stream : c->stream));
+    return MIRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// mirt_device_math.h — "mirt-math v1" on gfx950.
+//
+// The path-traced kernel must produce bit-identical fp32 results on the device and in any
+// independent CPU check, so every elementary function is a fixed sequence of correctly rounded
+// IEEE binary32 operations (+ - * / sqrt fma) — no OCML, no v_sin/v_cos/v_rcp approximations.
+// The translation unit is compiled with -ffp-contract=off; the only fused operations are the
+// explicit __builtin_fmaf calls (v_fma_f32).  Division and sqrt use hipcc's correctly rounded
+// expansions (-fhip-fp32-correctly-rounded-divide-sqrt, the default).
+//
+// Coefficients: tools/fit_poly.py (tests/test_math_spec.py checks this file against it).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MIRT_DEV __device__ __forceinline__
+
+namespace mirt {
+
+// constants exactly as the reference shader spells them (raytracer.wgsl:1-8)
+constexpr float kEpsilon  = 0.001f;
+constexpr float kPi       = 3.1415927f;
+constexpr float kFrac1Pi  = 0.31830987f;
+constexpr float kFracPi2  = 1.5707964f;
+constexpr float kTwoPi    = 6.2831855f;
+constexpr float kMinT     = 0.001f;
+constexpr float kMaxT     = 1000.0f;
+
+MIRT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MIRT_DEV float sqrt_(float a) { return __builtin_sqrtf(a); }
+MIRT_DEV float abs_(float a) { return __builtin_fabsf(a); }
+MIRT_DEV uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+MIRT_DEV float from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---- polynomial kernels: Horner, one fma per step, highest power first ----
+template <int N>
+MIRT_DEV float horner(const float (&c)[N], float z)
+{
+    float acc = c[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) acc = fma_(acc, z, c[i]);
+    return acc;
+}
+
+struct SinCos { float s, c; };
+
+// sin & cos together: nearest-integer quadrant by the magic-number trick, three-part pi/2
+// reduction (three fmas), two degree-3 polynomials in r*r, quadrant fix-up.
+MIRT_DEV SinCos sincos_(float x)
+{
+    constexpr float kSin[4] = { -0x1.5555560000000p-3f, 0x1.11110e0000000p-7f, -0x1.a013a80000000p-13f, 0x1.6dbe080000000p-19f };
+    constexpr float kCos[4] = { 0x1.5555560000000p-5f, -0x1.6c16c00000000p-10f, 0x1.a015c80000000p-16f, -0x1.2524f20000000p-22f };
+    constexpr float kTwoOverPi = 0.63661975f, kMagic = 12582912.0f;
+    constexpr float kHi = 1.5703125f, kMd = 4.837512969970703125e-4f, kLo = 7.54978995489188216e-8f;
+    x = (abs_(x) <= 1048576.0f) ? x : 0.0f;              // outside the reduction domain / NaN -> 0
+    const float kf = (x * kTwoOverPi + kMagic) - kMagic;
+    const int q = (int)kf;
+    float r = fma_(-kf, kHi, x);
+    r = fma_(-kf, kMd, r);
+    r = fma_(-kf, kLo, r);
+    const float z = r * r;
+    const float sr = fma_(r * z, horner(kSin, z), r);
+    const float cr = fma_(z * z, horner(kCos, z), fma_(-0.5f, z, 1.0f));
+    // q&1 swaps, q&2 negates sin, (q+1)&2 negates cos
+    const float s0 = (q & 1) ? cr : sr;
+    const float c0 = (q & 1) ? sr : cr;
+    SinCos o;
+    o.s = (q & 2) ? -s0 : s0;
+    o.c = ((q + 1) & 2) ? -c0 : c0;
+    return o;
+}
+
+MIRT_DEV float asin_core(float x, float z)
+{
+    constexpr float kAsin[6] = { 0x1.5555540000000p-3f, 0x1.3334300000000p-4f, 0x1.6d5bba0000000p-5f, 0x1.fd8da20000000p-6f, 0x1.18f91e0000000p-6f, 0x1.13fed40000000p-5f };
+    return fma_(x * z, horner(kAsin, z), x);
+}
+
+// acos with the argument clamped to [-1,1] (NaN behaves as 1).
+MIRT_DEV float acos_(float x)
+{
+    x = (x < 1.0f) ? x : 1.0f;
+    x = (x < -1.0f) ? -1.0f : x;
+    const float ax = abs_(x);
+    const bool small = ax <= 0.5f;
+    // both branches share one asin_core evaluation: pick its argument first
+    const float zb = (1.0f - ax) * 0.5f;
+    const float z = small ? x * x : zb;
+    const float a = small ? x : sqrt_(zb);
+    const float core = asin_core(a, z);
+    const float t = 2.0f * core;
+    const float big = (x > 0.0f) ? t : (kPi - t);
+    return small ? (kFracPi2 - core) : big;
+}
+
+// atan2 with one division: a = min/max; atan(a) = a + a*z*T(z); octant fix-ups.
+MIRT_DEV float atan2_(float y, float x)
+{
+    constexpr float kAtan[9] = { -0x1.5555540000000p-2f, 0x1.99983c0000000p-3f, -0x1.246cd20000000p-3f, 0x1.c3f1680000000p-4f, -0x1.6295f80000000p-4f, 0x1.0001c60000000p-4f, -0x1.25dc120000000p-5f, 0x1.ba9f660000000p-7f, -0x1.38de560000000p-9f };
+    const float ax = abs_(x), ay = abs_(y);
+    const bool xbig = ax > ay;
+    const float mx = xbig ? ax : ay;
+    const float mn = xbig ? ay : ax;
+    if (!(mx > 0.0f)) return 0.0f;
+    const float a = mn / mx;
+    const float z = a * a;
+    float r = fma_(a * z, horner(kAtan, z), a);
+    r = (ay > ax) ? (kFracPi2 - r) : r;
+    r = (x < 0.0f) ? (kPi - r) : r;
+    return (y < 0.0f) ? -r : r;
+}
+
+// log2 of a finite positive float.
+MIRT_DEV float log2_(float x)
+{
+    constexpr float kLog2[10] = { 0x1.7154760000000p+0f, -0x1.7154700000000p-1f, 0x1.ec70aa0000000p-2f, -0x1.715a700000000p-2f, 0x1.277a520000000p-2f, -0x1.eab7aa0000000p-3f, 0x1.a38c680000000p-3f, -0x1.87f6a20000000p-3f, 0x1.7a63a00000000p-3f, -0x1.b84fb60000000p-4f };
+    uint32_t u = bits(x);
+    int eadj = 0;
+    if (u < 0x00800000u) { x = x * 16777216.0f; u = bits(x); eadj = -24; }
+    int e = (int)(u >> 23) - 127;
+    uint32_t m = (u & 0x007fffffu) | 0x3f800000u;
+    if (m >= 0x3fb504f3u) { m -= 0x00800000u; e += 1; }
+    const float f = from_bits(m) - 1.0f;
+    return fma_(f, horner(kLog2, f), (float)(e + eadj));
+}
+
+// 2^y: nearest-integer split, degree-7 polynomial, two-step exponent scaling.
+MIRT_DEV float exp2_(float y)
+{
+    constexpr float kExp2[7] = { 0x1.62e4300000000p-1f, 0x1.ebfbe00000000p-3f, 0x1.c6b08e0000000p-5f, 0x1.3b2a1c0000000p-7f, 0x1.5d879e0000000p-10f, 0x1.4440000000000p-13f, 0x1.00a5800000000p-16f };
+    constexpr float kMagic = 12582912.0f;
+    if (!(y < 128.0f)) return __builtin_inff();
+    if (!(y >= -126.0f)) return 0.0f;
+    const float nf = (y + kMagic) - kMagic;
+    const float f = y - nf;
+    const int n = (int)nf;
+    const float p = fma_(f, horner(kExp2, f), 1.0f);
+    const int n1 = n >> 1, n2 = n - n1;
+    const float s1 = from_bits((uint32_t)(n1 + 127) << 23);
+    const float s2 = from_bits((uint32_t)(n2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+MIRT_DEV float pow_pos(float x, float y) { return (x > 0.0f) ? exp2_(y * log2_(x)) : 0.0f; }
+MIRT_DEV float exp_(float x) { return exp2_(x * 1.44269504f); }
+
+// ---- 3-vectors ----
+struct f3 { float x, y, z; };
+MIRT_DEV f3 mk(float x, float y, float z) { return f3{ x, y, z }; }
+MIRT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+MIRT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+MIRT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+MIRT_DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+MIRT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+// s*a + b with one fma per component
+MIRT_DEV f3 fma3(float s, f3 a, f3 b) { return mk(fma_(s, a.x, b.x), fma_(s, a.y, b.y), fma_(s, a.z, b.z)); }
+// path-traced dot: fma(az,bz, fma(ay,by, ax*bx))
+MIRT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+MIRT_DEV f3 normalize(f3 a) { return (1.0f / sqrt_(dot(a, a))) * a; }
+// parity-mode dot (nalgebra, no fusion): (a0*b0 + a1*b1) + a2*b2
+MIRT_DEV float dot_nofma(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+}  // namespace mirt
