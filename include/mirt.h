@@ -155,7 +155,9 @@ typedef struct MirtParams {
 /* Work counters of the last render on a context (rocprof-independent).  The ray/test/scatter
  * counters are filled only when MIRT_FLAG_COUNT_WORK was set. */
 typedef struct MirtStats {
-    double   kernel_ms;        /* hipEvent time of the render kernel(s) of the last call */
+    double   kernel_ms;        /* hipEvent time of the render kernel of the LAST render call */
+    double   kernel_ms_total;  /* summed over every render call since the previous mirt_ctx_get_stats */
+    uint64_t launches;         /* number of render calls in kernel_ms_total */
     uint64_t samples;          /* pixels x spp rendered by the last call */
     uint64_t rays;             /* rays traced (primary + scattered) */
     uint64_t sphere_tests;     /* ray-sphere discriminant evaluations */

@@ -1,0 +1,161 @@
+"""C-ABI behaviour on the GPU: error codes (same as the oracle's for the same inputs), context
+lifecycle, device-memory rendering into a torch tensor on torch's stream, device de-interleave,
+one-shot mirt_render."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import weekend_raytracer_wgpu_amd as m
+from weekend_raytracer_wgpu_amd import _abi
+from helpers import assert_images_equal, layer_scene_data, scene_data, simple_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def _status(fn):
+    with pytest.raises(m.MirtError) as e:
+        fn()
+    return e.value.status
+
+
+def test_render_before_set_scene():
+    ctx = m.Context(0)
+    assert _status(lambda: ctx.render(m.make_params(8, 8, 1))) == _abi.MIRT_ERR_NO_SCENE
+    ctx.close()
+
+
+@pytest.mark.parametrize("kw,status", [
+    (dict(width=0), "MIRT_ERR_VIEWPORT_SIZE"), (dict(height=0), "MIRT_ERR_VIEWPORT_SIZE"),
+    (dict(spp=0), "MIRT_ERR_SPP_ZERO"), (dict(mode=7), "MIRT_ERR_BAD_MODE"),
+    (dict(row_begin=10, row_end=5), "MIRT_ERR_BAD_ROWS"), (dict(row_end=99), "MIRT_ERR_BAD_ROWS"),
+    (dict(tile_rows=4, n_parts=2, part=2), "MIRT_ERR_BAD_ROWS"),
+])
+def test_param_errors_match_oracle(gpu_ctx, oracle, kw, status):
+    sd = layer_scene_data(32, 24)
+    gpu_ctx.set_scene(sd)
+    args = dict(width=32, height=24, spp=2)
+    args.update(kw)
+    p = m.make_params(args.pop("width"), args.pop("height"), args.pop("spp"), **args)
+    got = _status(lambda: gpu_ctx.render(p)) if p.width and p.height else None
+    if got is None:      # numpy cannot even allocate a 0-sized frame the same way; call the ABI directly
+        buf = (C.c_uint8 * 16)()
+        got = m.lib().mirt_ctx_render(gpu_ctx._h, C.byref(p), buf, 16)
+    assert _abi.STATUS[got] == status
+    assert _abi.STATUS[oracle.render_status(sd.as_c(), p)] == status
+
+
+def test_scene_errors_match_oracle(gpu_ctx, oracle):
+    w, h = 16, 16
+    cam = simple_camera(w, h)
+    one = [m.Sphere.new((0, 0, 0), 1.0, 0).to_c()]
+    # parity mode needs material_data[2] (layer.rs:345-349)
+    two_mats, tex = m.flatten_materials([m.Material.Metal(m.Texture.new_from_color((1, 1, 1)), 0.1)] * 2)
+    sd = m.SceneData(cam, one, two_mats, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, 1)
+    assert _abi.STATUS[_status(lambda: gpu_ctx.render(p))] == "MIRT_ERR_MATERIAL_INDEX"
+    assert _abi.STATUS[oracle.render_status(sd.as_c(), p)] == "MIRT_ERR_MATERIAL_INDEX"
+    # PT: sphere pointing past the material table
+    sd2 = m.SceneData(cam, [m.Sphere.new((0, 0, 0), 1.0, 5).to_c()], two_mats, tex)
+    gpu_ctx.set_scene(sd2)
+    p = m.make_params(w, h, 1, mode=m.MIRT_MODE_PT)
+    assert _abi.STATUS[_status(lambda: gpu_ctx.render(p))] == "MIRT_ERR_MATERIAL_INDEX"
+    assert _abi.STATUS[oracle.render_status(sd2.as_c(), p)] == "MIRT_ERR_MATERIAL_INDEX"
+    # texture descriptor reaching past the texel table
+    bad = list(two_mats)
+    bad[0] = _abi.MirtMaterial(0, _abi.MirtTextureDescriptor(4, 4, 0), m.TextureDescriptor.empty(), 0.0)
+    sd3 = m.SceneData(cam, one, bad, tex)
+    gpu_ctx.set_scene(sd3)
+    assert _abi.STATUS[_status(lambda: gpu_ctx.render(p))] == "MIRT_ERR_TEXEL_RANGE"
+    assert _abi.STATUS[oracle.render_status(sd3.as_c(), p)] == "MIRT_ERR_TEXEL_RANGE"
+    # Hosek flag without a sky blob
+    sd4 = scene_data("single_sphere", w, h)
+    gpu_ctx.set_scene(sd4)
+    p = m.make_params(w, h, 1, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_SKY_HOSEK)
+    assert _abi.STATUS[_status(lambda: gpu_ctx.render(p))] == "MIRT_ERR_SKY"
+
+
+def test_scene_too_large_and_null_pointers(gpu_ctx):
+    cam = simple_camera(8, 8)
+    mats, tex = m.flatten_materials([m.Material.Dielectric(1.5)] * 3)
+    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 3000          # 96 KB > LDS budget
+    assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
+    lib = m.lib()
+    assert lib.mirt_ctx_set_scene(gpu_ctx._h, None) == _abi.MIRT_ERR_NULL_POINTER
+    assert lib.mirt_ctx_render(gpu_ctx._h, None, None, 0) == _abi.MIRT_ERR_NULL_POINTER
+    assert lib.mirt_ctx_create(99, C.byref(C.c_void_p())) == _abi.MIRT_ERR_NO_DEVICE
+    assert b"out of range" in lib.mirt_last_error()
+
+
+def test_out_buffer_too_small(gpu_ctx):
+    sd = layer_scene_data(32, 24)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(32, 24, 2)
+    buf = (C.c_uint8 * 100)()
+    assert m.lib().mirt_ctx_render(gpu_ctx._h, C.byref(p), buf, 100) == _abi.MIRT_ERR_OUT_BUFFER
+
+
+def test_one_shot_render(oracle):
+    w, h = 64, 48
+    sd = layer_scene_data(w, h)
+    p = m.make_params(w, h, 2)
+    out = np.zeros((h, w, 4), np.uint8)
+    c = sd.as_c()
+    assert m.lib().mirt_render(C.byref(c), C.byref(p), 0, out.ctypes.data_as(C.c_void_p), out.nbytes) == 0
+    assert_images_equal(out, oracle.render(sd, p), "mirt_render")
+
+
+def test_render_into_torch_tensor_and_device_deinterleave(gpu_ctx):
+    """The bench path: frames stay in HBM; kernels run on torch's current stream."""
+    import torch
+    w, h, spp = 96, 50, 24
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT)
+    want = gpu_ctx.render(base)
+    frame = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1)
+    got = frame.step()
+    torch.cuda.synchronize()
+    assert_images_equal(got.cpu().numpy(), want, "render_device world=1")
+    # emulate 4 ranks on one GPU: render each part into its slot, de-interleave on the device
+    world, tr = 4, 4
+    max_rows = m.multi_gpu.max_part_rows(base, world, tr)
+    parts = torch.zeros((world, max_rows, w, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        pr = m.multi_gpu.part_params(base, r, world, tr)
+        rows = m.params_out_rows(pr)
+        gpu_ctx.render_device(pr, parts[r].data_ptr(), rows * w * 4, stream)
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    gpu_ctx.deinterleave_device(m.multi_gpu.part_params(base, 0, world, tr), parts.data_ptr(), max_rows * w * 4,
+                                out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    assert_images_equal(out.cpu().numpy(), want, "device de-interleave")
+    st = gpu_ctx.stats()
+    assert st["launches"] == world + 1 and st["kernel_ms_total"] >= st["kernel_ms"] > 0
+
+
+def test_set_camera_only(gpu_ctx, oracle):
+    w, h = 64, 48
+    sd = layer_scene_data(w, h)
+    gpu_ctx.set_scene(sd)
+    cam2 = simple_camera(w, h, eye=(0, 2, 9), vfov=40.0)
+    gpu_ctx.set_camera(cam2)
+    p = m.make_params(w, h, 2)
+    sd2 = m.SceneData(cam2, list(sd.spheres), list(sd.materials), sd.texels)
+    assert_images_equal(gpu_ctx.render(p), oracle.render(sd2, p), "set_camera")
+
+
+def test_many_contexts_and_reuse(oracle):
+    w, h = 32, 24
+    sd = layer_scene_data(w, h)
+    p = m.make_params(w, h, 2)
+    want = oracle.render(sd, p)
+    for _ in range(3):
+        with m.Context(0) as ctx:
+            ctx.set_scene(sd)
+            for _ in range(70):          # wraps the 64-entry event pool
+                img = ctx.render(p)
+            assert_images_equal(img, want, "reuse")
+            assert ctx.stats()["launches"] == 70

@@ -1,0 +1,168 @@
+"""Parity proper (MI355X): path-traced mode (behaviours of reference src/raytracer/raytracer.wgsl)
+through the C ABI against the CPU oracle: RGBA8 u8-exact, linear (un-tonemapped) output u8-exact,
+and the work counters — every branch decision of every path — equal."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import weekend_raytracer_wgpu_amd as m
+from helpers import GOLDEN, assert_images_equal, scene_data, simple_camera
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+GOLD = np.load(GOLDEN / "images_v1.npz")
+LINEAR = m.MIRT_FLAG_NO_TONEMAP | m.MIRT_FLAG_NO_SRGB
+COUNTERS = ["rays", "sphere_tests", "roots", "hits", "scatter", "sky_misses"]
+
+
+def _render(ctx, sd, p):
+    ctx.set_scene(sd)
+    return ctx.render(p)
+
+
+@pytest.mark.parametrize("name", [n for n in GOLD.files if n.startswith("pt_")])
+def test_pt_goldens(gpu_ctx, name):
+    import make_goldens
+    sd, p = make_goldens.case_inputs(name)
+    assert_images_equal(_render(gpu_ctx, sd, p), GOLD[name], name)
+
+
+@pytest.mark.parametrize("scene,w,h,spp", [("single_sphere", 96, 64, 8), ("three_spheres", 128, 72, 16),
+                                            ("three_spheres", 61, 47, 130), ("earth", 128, 72, 16),
+                                            ("main_rs_scene", 128, 72, 70), ("rtiow_final", 64, 36, 4),
+                                            ("three_spheres", 1, 1, 1), ("three_spheres", 3, 1, 64), ("earth", 1, 5, 65)])
+@pytest.mark.parametrize("flags", [0, LINEAR])
+def test_pt_vs_oracle_images_and_counters(gpu_ctx, oracle, scene, w, h, spp, flags):
+    sd = scene_data(scene, w, h)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags | m.MIRT_FLAG_COUNT_WORK)
+    got = _render(gpu_ctx, sd, p)
+    gs = gpu_ctx.stats()
+    want = oracle.render(sd, p)
+    os_ = oracle.stats()
+    assert_images_equal(got, want, f"{scene} {w}x{h} spp{spp} flags{flags}")
+    assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+    assert gs["samples"] == w * h * spp
+    # the counting build and the plain build produce the same image
+    p2 = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags)
+    assert_images_equal(gpu_ctx.render(p2), want, "plain build")
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2, 4, 10])
+def test_bounce_limits(gpu_ctx, oracle, bounces):
+    w, h = 64, 48
+    sd = scene_data("main_rs_scene", w, h)
+    p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=LINEAR)
+    assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), f"bounces={bounces}")
+
+
+@pytest.mark.parametrize("seed", [1, 0xFFFFFFFF, 0x123456789ABCDEF0])
+def test_seeds(gpu_ctx, oracle, seed):
+    w, h = 64, 48
+    sd = scene_data("three_spheres", w, h)
+    p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, seed=seed)
+    assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), f"seed={seed:#x}")
+
+
+def test_sample_begin_offsets_the_stream(gpu_ctx, oracle):
+    w, h = 48, 32
+    sd = scene_data("three_spheres", w, h)
+    p = m.make_params(w, h, 14, mode=m.MIRT_MODE_PT, sample_begin=10, flags=LINEAR)
+    assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), "sample_begin")
+
+
+def test_hosek_sky_blob(gpu_ctx, oracle):
+    w, h = 64, 48
+    sd = scene_data("three_spheres", w, h)
+    sky = m._abi.MirtSkyState()
+    for c in range(3):
+        for i, v in enumerate([-1.1, -0.3, 0.5, 1.2, -2.5, 0.4, 0.2, 1.5, 0.6]):
+            sky.params[9 * c + i] = v * (1.0 + 0.1 * c)
+        sky.radiances[c] = 1.0 + c
+    sky.sun_direction[:] = [0.0, 0.6, 0.8, 0.0]
+    sd.sky = sky
+    for flags in (m.MIRT_FLAG_SKY_HOSEK, m.MIRT_FLAG_SKY_HOSEK | LINEAR):
+        p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, flags=flags | m.MIRT_FLAG_COUNT_WORK)
+        got = _render(gpu_ctx, sd, p)
+        gs = gpu_ctx.stats()
+        assert_images_equal(got, oracle.render(sd, p), f"hosek flags={flags}")
+        os_ = oracle.stats()
+        assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+
+
+def test_missing_material_id_and_every_material(gpu_ctx, oracle):
+    """All five scatter branches incl. the pink 'missing material' one (wgsl:309-314), textures > 1x1
+    on metal and checker, fuzz 0 and 1, ior < 1."""
+    rng = np.random.default_rng(7)
+    tex_img = (rng.random((8, 16, 3)) * 255).astype(np.uint8)
+    T = m.Texture
+    mats = [m.Material.Lambertian(T.new_from_rgb8(tex_img)),
+            m.Material.Metal(T.new_from_rgb8(tex_img[:4, :4]), 0.0),
+            m.Material.Metal(T.new_from_color((0.9, 0.9, 0.9)), 1.0),
+            m.Material.Dielectric(1.5), m.Material.Dielectric(0.7),
+            m.Material.Checkerboard(even=T.new_from_rgb8(tex_img[:2, :8]), odd=T.new_from_color((0.2, 0.3, 0.4)))]
+    gm, texels = m.flatten_materials(mats)
+    bogus = m._abi.MirtMaterial(9, m.TextureDescriptor.empty(), m.TextureDescriptor.empty(), 0.0)
+    gm.append(bogus)
+    spheres = [m.Sphere.new((0, -100.5, 0), 100.0, 5).to_c()] + \
+              [m.Sphere.new((-3 + 1.0 * i, 0.0, float(rng.uniform(-1, 1))), 0.5, i).to_c() for i in range(7)]
+    w, h = 160, 90
+    sd = m.SceneData(simple_camera(w, h, eye=(0, 0.5, 5), vfov=50, aperture=0.2, focus=5), spheres, gm, texels)
+    p = m.make_params(w, h, 32, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_COUNT_WORK)
+    got = _render(gpu_ctx, sd, p)
+    gs = gpu_ctx.stats()
+    assert_images_equal(got, oracle.render(sd, p), "all materials")
+    os_ = oracle.stats()
+    assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+    assert all(n > 0 for n in gs["scatter"]), gs["scatter"]
+
+
+def test_tiles_and_sample_split_reassemble(gpu_ctx):
+    w, h = 96, 77
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    base = m.make_params(w, h, 48, mode=m.MIRT_MODE_PT)
+    full = gpu_ctx.render(base)
+    for world, tr in [(2, 4), (8, 4), (3, 16)]:
+        parts = np.zeros((world, m.multi_gpu.max_part_rows(base, world, tr), w, 4), np.uint8)
+        for r in range(world):
+            img = gpu_ctx.render(m.multi_gpu.part_params(base, r, world, tr))
+            parts[r, :img.shape[0]] = img
+        assert_images_equal(m.multi_gpu.assemble_host(parts, base, world, tr), full, f"{world}x{tr}")
+    assert_images_equal(gpu_ctx.render(base), full, "determinism")
+
+
+def test_raytracer_object_end_to_end(oracle):
+    scene, cam = m.scenes.three_spheres()
+    rp = m.RenderParams(camera=cam, viewport_size=(96, 64), sampling=m.SamplingParams(64, 2, 8))
+    rt = m.Raytracer(scene, rp)
+    got = rt.render()
+    want = oracle.render(rt.scene_data(), m.make_params(96, 64, 64, mode=m.MIRT_MODE_PT, num_bounces=8))
+    assert_images_equal(got, want, "Raytracer.render")
+    with pytest.raises(m.RenderParamsValidationError):
+        rt.set_render_params(m.RenderParams(camera=cam, viewport_size=(96, 64), sampling=m.SamplingParams(64, 5, 8)))
+    rt.close()
+
+
+def test_full_size_pt_properties(gpu_ctx, oracle):
+    """BASELINE size (1920x1080; spp cut to 64 so the oracle rows finish in seconds): sampled rows
+    vs the oracle, 8-way tile partition == whole frame, counters == analytic identities."""
+    w, h, spp = 1920, 1080, 64
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_COUNT_WORK)
+    full = gpu_ctx.render(base)
+    st = gpu_ctx.stats()
+    assert st["samples"] == w * h * spp and st["sphere_tests"] == 3 * st["rays"]
+    assert st["rays"] == st["hits"] + st["sky_misses"] and st["hits"] == sum(st["scatter"])
+    for rb in (0, 400, 700, 1079):
+        band = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, row_begin=rb, row_end=rb + 1)
+        assert_images_equal(full[rb:rb + 1], oracle.render(sd, band), f"row {rb} vs oracle")
+    plain = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT)
+    parts = np.zeros((8, m.multi_gpu.max_part_rows(plain, 8, 4), w, 4), np.uint8)
+    for r in range(8):
+        img = gpu_ctx.render(m.multi_gpu.part_params(plain, r, 8, 4))
+        parts[r, :img.shape[0]] = img
+    assert_images_equal(m.multi_gpu.assemble_host(parts, plain, 8, 4), full, "8-way tiles 1080p")

@@ -15,3 +15,4 @@ from .raytracer import *  # noqa: F401,F403
 from . import scenes
 
 __version__ = "0.1.0"
+from . import multi_gpu

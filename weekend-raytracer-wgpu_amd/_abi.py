@@ -96,13 +96,15 @@ class MirtParams(C.Structure):
 
 
 class MirtStats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("samples", C.c_uint64), ("rays", C.c_uint64),
+    _fields_ = [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64),
+                ("samples", C.c_uint64), ("rays", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("roots", C.c_uint64), ("hits", C.c_uint64),
                 ("scatter", C.c_uint64 * 5), ("sky_misses", C.c_uint64),
                 ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64)]
 
     def as_dict(self) -> dict:
-        return {"kernel_ms": self.kernel_ms, "samples": self.samples, "rays": self.rays,
+        return {"kernel_ms": self.kernel_ms, "kernel_ms_total": self.kernel_ms_total, "launches": self.launches,
+                "samples": self.samples, "rays": self.rays,
                 "sphere_tests": self.sphere_tests, "roots": self.roots, "hits": self.hits,
                 "scatter": list(self.scatter), "sky_misses": self.sky_misses,
                 "lane_iterations": self.lane_iterations, "wave_iterations": self.wave_iterations}

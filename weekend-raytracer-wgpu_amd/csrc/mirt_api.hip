@@ -76,6 +76,8 @@ uint32_t jenkins_hash(uint32_t x)
     return x;
 }
 
+constexpr int kEventPool = 64;
+
 constexpr float kRustPi = 3.14159265358979323846f;   // std::f32::consts::PI
 
 struct V3 { float x, y, z; };
@@ -106,8 +108,13 @@ struct MirtContext {
     int         device = -1;
     int         cu_count = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t  ev_begin = nullptr, ev_end = nullptr;
-    bool        timing_pending = false;
+    // hipEvent pairs around every render kernel, recorded on the stream the kernel runs on;
+    // drained (summed) by mirt_ctx_get_stats so that no host sync sits inside a timed loop.
+    std::vector<hipEvent_t> ev_begin, ev_end;
+    size_t      ev_used = 0;
+    double      ms_folded = 0.0;      // time of pairs already folded because the pool wrapped
+    uint64_t    launches_folded = 0;
+    double      last_ms = 0.0;
 
     // resident scene
     bool     have_scene = false;
@@ -260,8 +267,13 @@ int mirt_ctx_create(int device, MirtContext** out)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
+    for (int i = 0; i < kEventPool && e == hipSuccess; ++i) {
+        hipEvent_t a = nullptr, b = nullptr;
+        e = hipEventCreate(&a);
+        if (e == hipSuccess) e = hipEventCreate(&b);
+        if (a) c->ev_begin.push_back(a);
+        if (b) c->ev_end.push_back(b);
+    }
     if (e == hipSuccess) e = hipMalloc(&c->d_cam, sizeof(MirtGpuCamera));
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters);
@@ -283,8 +295,8 @@ void mirt_ctx_destroy(MirtContext* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out);
-    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
-    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -375,8 +387,28 @@ static int check_params(const MirtContext* c, const MirtParams* p)
     return MIRT_OK;
 }
 
+// Sum the elapsed time of every recorded event pair into ms_folded and free the pool.
+static int fold_events(MirtContext* c)
+{
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(c->ev_end[i]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+        c->ms_folded += ms;
+        c->launches_folded += 1;
+        c->last_ms = ms;
+    }
+    c->ev_used = 0;
+    return MIRT_OK;
+}
+
 static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream)
 {
+    if (c->ev_used == c->ev_begin.size()) {      // pool exhausted: fold (one sync per 64 launches)
+        const int rc = fold_events(c);
+        if (rc != MIRT_OK) return rc;
+    }
+    const size_t ev = c->ev_used;
     const uint32_t rows = out_rows(p);
     const uint64_t npix = (uint64_t)rows * p->width;
     const bool count = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_COUNT_WORK);
@@ -402,11 +434,11 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), stream));
     if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
-    HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
     else HIP_TRY(mirt::launch_pt(a, blocks, count, stream));
-    HIP_TRY(hipEventRecord(c->ev_end, stream));
-    c->timing_pending = true;
+    HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
+    c->ev_used = ev + 1;
     c->stats_counted = count;
     c->stats = MirtStats{};
     c->stats.samples = npix * p->spp;
@@ -444,7 +476,7 @@ int mirt_ctx_synchronize(MirtContext* c)
 {
     if (!c) return fail(MIRT_ERR_NULL_POINTER, "ctx is null");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->timing_pending) HIP_TRY(hipEventSynchronize(c->ev_end));
+    for (size_t i = 0; i < c->ev_used; ++i) HIP_TRY(hipEventSynchronize(c->ev_end[i]));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MIRT_OK;
 }
@@ -453,24 +485,26 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
 {
     if (!c || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->timing_pending) {
-        HIP_TRY(hipEventSynchronize(c->ev_end));
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
-        c->stats.kernel_ms = ms;
-        if (c->stats_counted) {
-            unsigned long long h[mirt::kNumCounters];
-            HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-            c->stats.rays = h[mirt::kCntRays];
-            c->stats.sphere_tests = h[mirt::kCntTests];
-            c->stats.roots = h[mirt::kCntRoots];
-            c->stats.hits = h[mirt::kCntHits];
-            for (int i = 0; i < 5; ++i) c->stats.scatter[i] = h[mirt::kCntScatter0 + i];
-            c->stats.sky_misses = h[mirt::kCntSky];
-            c->stats.lane_iterations = h[mirt::kCntLaneIters];
-            c->stats.wave_iterations = h[mirt::kCntWaveIters];
-        }
-        c->timing_pending = false;
+    const bool had_launch = c->ev_used > 0;
+    const int rc = fold_events(c);
+    if (rc != MIRT_OK) return rc;
+    c->stats.kernel_ms = c->last_ms;
+    c->stats.kernel_ms_total = c->ms_folded;
+    c->stats.launches = c->launches_folded;
+    c->ms_folded = 0.0;
+    c->launches_folded = 0;
+    if (had_launch && c->stats_counted) {
+        unsigned long long h[mirt::kNumCounters];
+        HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+        c->stats.rays = h[mirt::kCntRays];
+        c->stats.sphere_tests = h[mirt::kCntTests];
+        c->stats.roots = h[mirt::kCntRoots];
+        c->stats.hits = h[mirt::kCntHits];
+        for (int i = 0; i < 5; ++i) c->stats.scatter[i] = h[mirt::kCntScatter0 + i];
+        c->stats.sky_misses = h[mirt::kCntSky];
+        c->stats.lane_iterations = h[mirt::kCntLaneIters];
+        c->stats.wave_iterations = h[mirt::kCntWaveIters];
+        c->stats_counted = false;
     }
     *out = c->stats;
     return MIRT_OK;
