@@ -55,6 +55,21 @@ def algorithmic_flops(st: dict, hosek: bool = False) -> float:
     return float(f)
 
 
+def profiled_traffic(kernel: str):
+    """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_summary.json, written by tools/summarize_profile.py: separate --pmc passes,
+    FETCH_SIZE x2 gfx950 correction).  None if no summary for this kernel exists."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json")):
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if kernel.startswith(d.get("kernel", "\0")) and "hbm_bytes_per_launch" in d.get("derived", {}):
+            best = (d["derived"]["hbm_bytes_per_launch"], f.name)
+    return best
+
+
 def build_scene(m):
     scene, cam = m.scenes.three_spheres()
     mats, texels = m.flatten_materials(scene.materials)
@@ -75,7 +90,7 @@ def cpu_baseline(m, sd, target_seconds: float = 15.0) -> dict:
     p = m.make_params(WIDTH, HEIGHT, 1, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
     ob.render(sd, p, n_threads=cores)
     probe_s = ob.stats()["kernel_ms"] / 1e3
-    spp = int(max(1, min(64, round(target_seconds / max(probe_s, 1e-3)))))
+    spp = int(max(1, min(SPP, round(target_seconds / max(probe_s, 1e-3)))))
     p = m.make_params(WIDTH, HEIGHT, spp, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
     ob.render(sd, p, n_threads=cores)
     secs = ob.stats()["kernel_ms"] / 1e3
@@ -163,6 +178,7 @@ def main() -> int:
         total_samples = WIDTH * HEIGHT * SPP
         value = total_samples * args.steps / elapsed / 1e6
         flops = algorithmic_flops(work)
+        traffic = profiled_traffic("render_pt_kernel<false") if world == 1 else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
         out_bytes = frame.rows * WIDTH * 4
         in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96
@@ -191,7 +207,8 @@ def main() -> int:
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
                 "kernel": "render_pt_kernel<false,false>",
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),

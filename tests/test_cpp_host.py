@@ -1,0 +1,57 @@
+"""The C++ mirror of the reference interface (weekend-raytracer-wgpu_amd/host/): table layout and
+validation without a GPU; Layer::new -> set_global_data -> set_data end to end on the GPU."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import weekend_raytracer_wgpu_amd as m
+from helpers import GOLDEN, assert_images_equal, layer_scene_data
+
+ROOT = Path(__file__).resolve().parent.parent
+DEMO = ROOT / "weekend-raytracer-wgpu_amd" / "host" / "layer_demo"
+
+
+@pytest.fixture(scope="module")
+def ppms(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ppm")
+    out = {}
+    for name in ("moon", "earthmap"):
+        a = np.load(GOLDEN / f"{name}_1024x512_rgb8.npz")["rgb8"]
+        p = d / f"{name}.ppm"
+        with open(p, "wb") as f:
+            f.write(b"P6\n1024 512\n255\n")
+            f.write(a.tobytes())
+        out[name] = str(p)
+    if not DEMO.exists():
+        subprocess.run(["make", "-C", str(DEMO.parent)], check=True, capture_output=True)
+    return out
+
+
+def test_cpp_layer_tables_and_validation(ppms):
+    r = subprocess.run([str(DEMO), "--host-only", ppms["moon"], ppms["earthmap"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "materials 5 texels 1048579 offsets 0 1 2 524290 524291 ids 3 0 1 2 0"
+    cam = m.GpuCamera.new(m.FlyCameraController.default().renderer_camera(), (800, 600)).c
+    want = "camera llc %.9g %.9g %.9g" % tuple(cam.lower_left_corner)
+    assert lines[1] == want
+    assert lines[2] == "validate: MIRT_ERR_MAX_SAMPLES_MULTIPLE"
+
+
+def test_cpp_texture_errors(ppms, tmp_path):
+    r = subprocess.run([str(DEMO), "--host-only", str(tmp_path / "missing.ppm"), ppms["earthmap"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "TextureError::IoError" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_layer_set_data_matches_oracle(ppms, tmp_path, oracle):
+    out = tmp_path / "frame.rgba"
+    w, h, spp = 200, 150, 21
+    r = subprocess.run([str(DEMO), ppms["moon"], ppms["earthmap"], str(w), str(h), str(spp), str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(out, dtype=np.uint8).reshape(h, w, 4)
+    want = oracle.render(layer_scene_data(w, h), m.make_params(w, h, spp))
+    assert_images_equal(got, want, "C++ Layer::set_data")

@@ -114,6 +114,7 @@ def test_render_into_torch_tensor_and_device_deinterleave(gpu_ctx):
     gpu_ctx.set_scene(sd)
     base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT)
     want = gpu_ctx.render(base)
+    gpu_ctx.stats()                     # drain: count only the launches below
     frame = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1)
     got = frame.step()
     torch.cuda.synchronize()

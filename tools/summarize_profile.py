@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh run (gpurun_out/prof_<tag>/) into committed artefacts:
+
+    profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+    profiles/<tag>_pmc_summary.json   per-launch averages of every collected counter for the render
+                                      kernel + derived metrics (VALU issue busy %, lane utilisation,
+                                      clock, HBM bytes with the gfx950 FETCH_SIZE x2 correction)
+
+Usage: python tools/summarize_profile.py r01 [kernel-substring]
+"""
+from __future__ import annotations
+
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+N_CU, SIMD_PER_CU = 256, 4
+
+
+def main() -> int:
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "render_pt_kernel<false"
+    src = ROOT / "gpurun_out" / f"prof_{tag}"
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+    stats = glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True)
+    if not stats:
+        print("no kernel_stats.csv under", src)
+        return 1
+    shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
+    kernel_ns = None
+    for row in csv.DictReader(open(stats[0])):
+        if needle in row["Name"]:
+            kernel_ns = float(row["AverageNs"])
+            calls = int(row["Calls"])
+    counters: dict[str, list[float]] = collections.defaultdict(list)
+    meta = {}
+    for f in sorted(glob.glob(str(src / "pmc*" / "**" / "*_counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if needle in row["Kernel_Name"]:
+                counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                meta = {"grid_size": int(row["Grid_Size"]), "workgroup_size": int(row["Workgroup_Size"]),
+                        "vgpr_count": int(row["VGPR_Count"]), "sgpr_count": int(row["SGPR_Count"]),
+                        "lds_block_size": int(row["LDS_Block_Size"]), "scratch_size": int(row["Scratch_Size"])}
+    avg = {k: sum(v) / len(v) for k, v in counters.items()}
+    d: dict[str, float] = {}
+    secs = kernel_ns * 1e-9
+    if "GRBM_GUI_ACTIVE" in avg:
+        cycles = avg["GRBM_GUI_ACTIVE"] / 8.0                   # rocprofv3 sums the 8 XCDs
+        d["clock_ghz"] = cycles / secs / 1e9                     # NB: profiled pass; kernel time from the trace pass
+        simd_cycles = cycles * N_CU * SIMD_PER_CU
+        if "SQ_INSTS_VALU" in avg:
+            # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles at full rate
+            d["valu_issue_busy_pct"] = 100.0 * avg["SQ_INSTS_VALU"] * 2.0 / simd_cycles
+        if "SQ_ACTIVE_INST_VALU" in avg:
+            # SQ_ACTIVE_INST_* count quad-cycles per wave; two waves' VALU ops overlap on one SIMD
+            d["valu_active_pct_of_pipe"] = 100.0 * avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (2.0 * simd_cycles)
+    if "SQ_THREAD_CYCLES_VALU" in avg and "SQ_ACTIVE_INST_VALU" in avg:
+        d["valu_lane_utilization_pct"] = 100.0 * avg["SQ_THREAD_CYCLES_VALU"] / (avg["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if "SQ_WAVE_CYCLES" in avg:
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            if k in avg:
+                d[k.lower() + "_share_of_wave_cycles_pct"] = 100.0 * avg[k] / avg["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in avg:
+        d["hbm_read_bytes"] = avg["FETCH_SIZE"] * 1024.0 * 2.0   # gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads
+    if "WRITE_SIZE" in avg:
+        d["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024.0
+    if "hbm_read_bytes" in d and "hbm_write_bytes" in d:
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+        d["hbm_gbs"] = d["hbm_bytes_per_launch"] / secs / 1e9
+    if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
+        d["l2_hit_rate_pct"] = 100.0 * avg["TCC_HIT_sum"] / max(1.0, avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
+    out = {"tag": tag, "kernel": needle, "kernel_avg_ms_trace_pass": kernel_ns / 1e6, "calls_in_trace": calls,
+           "dispatch": meta, "counters_per_launch_avg": avg, "derived": d,
+           "notes": ["each --pmc group was collected in its own run (tools/profile_bench.sh)",
+                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of coalesced reads); WRITE_SIZE taken as is",
+                     "kernel time is from the un-counted --kernel-trace --stats pass"]}
+    (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    print(json.dumps(d, indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
