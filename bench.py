@@ -133,7 +133,8 @@ def main() -> int:
     sd = build_scene(m)
     ctx = m.Context(local_rank)
     ctx.set_scene(sd)                                   # inputs resident in HBM before the timed region
-    base = m.make_params(WIDTH, HEIGHT, SPP, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
+    base = m.make_params(WIDTH, HEIGHT, SPP, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES,
+                         flags=int(os.environ.get("MIRT_BENCH_FLAGS", "0"), 0))      # e.g. 0x10 strip / 0x20 pool (A/B runs)
     frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows)
 
     def barrier():

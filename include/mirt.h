@@ -127,7 +127,11 @@ enum {
     MIRT_FLAG_SKY_HOSEK      = 1u << 0, /* sky = Hosek-Wilkie blob (wgsl:154-166,316-343); default: RTIOW gradient */
     MIRT_FLAG_NO_TONEMAP     = 1u << 1, /* skip uncharted2 (wgsl:83-103) */
     MIRT_FLAG_NO_SRGB        = 1u << 2, /* skip the sRGB OETF the Bgra8UnormSrgb surface applies (main.rs:465) */
-    MIRT_FLAG_COUNT_WORK     = 1u << 3  /* run the counting build of the kernel: fills MirtStats work counters */
+    MIRT_FLAG_COUNT_WORK     = 1u << 3, /* run the counting build of the kernel: fills MirtStats work counters */
+    /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the
+     * pooled kernel (paths queued by material in LDS) when spp >= 48, else the strip kernel. */
+    MIRT_FLAG_KERNEL_STRIP   = 1u << 4, /* force the strip kernel (wave = 64 samples of one pixel) */
+    MIRT_FLAG_KERNEL_POOL    = 1u << 5  /* force the pooled kernel */
 };
 
 /* What one render call computes.  The image is `width x height`; this call renders the rows

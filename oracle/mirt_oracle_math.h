@@ -87,6 +87,21 @@ static inline void om_sincos(float x, float* s_out, float* c_out)
     *c_out = c;
 }
 static inline float om_sin(float x) { float s, c; om_sincos(x, &s, &c); return s; }
+
+/* Sign of sin(x) in {-1, 0, +1} from the SAME argument reduction as om_sincos, without the
+ * polynomials: for |r| <= pi/4, cos(r) > 0 and sin(r) has the sign of r (0 iff r == 0). */
+static inline int om_sin_sign(float x)
+{
+    if (!(fabsf(x) <= 1048576.0f)) x = 0.0f;
+    float kf = (x * OM_TWO_OVER_PI + OM_RND_MAGIC) - OM_RND_MAGIC;
+    int32_t q = (int32_t)kf;
+    float r = MFMA(-kf, OM_PIO2_HI, x);
+    r = MFMA(-kf, OM_PIO2_MD, r);
+    r = MFMA(-kf, OM_PIO2_LO, r);
+    int sr = (r > 0.0f) - (r < 0.0f);
+    int base = (q & 1) ? 1 : sr;            /* odd quadrant: +-cos(r), cos(r) > 0 */
+    return (q & 2) ? -base : base;
+}
 static inline float om_cos(float x) { float s, c; om_sincos(x, &s, &c); return c; }
 
 /* ---- asin kernel on [0, 0.5]: asin(x) = x + x*z*A(z), z = x*x ---- */

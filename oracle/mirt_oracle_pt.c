@@ -27,6 +27,9 @@
  *       exactly as wgsl:154-166, 316-343.
  *   S7  texture index: offset + i*width + j, clamped to the table (wgsl:377-387; WGSL's robust
  *       buffer access makes out-of-range reads implementation-defined).
+ *   S9  checkerboard: the sign of sin(5x)*sin(5y)*sin(5z) (wgsl:301-302) is taken from the signs
+ *       of the three sines (exact argument reduction, no polynomial); it differs from the float
+ *       product only if that product would underflow to zero.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -264,9 +267,9 @@ static inline void scatter(const tctx_t* T, const tray_t* in, const thit_t* hit,
     }
     case 3: {   /* scatterCheckerboard wgsl:300-307 */
         T->st->scatter[3]++;
-        float sx = om_sin(5.0f * hit->p.x), sy = om_sin(5.0f * hit->p.y), sz = om_sin(5.0f * hit->p.z);
-        float sines = (sx * sy) * sz;
-        scatter_lambertian(T, hit, (sines < 0.0f) ? m->desc1 : m->desc2, st, out_ray, atten);
+        /* S9: `sin(5x)*sin(5y)*sin(5z) < 0` decided from the signs of the three sines */
+        int sines = om_sin_sign(5.0f * hit->p.x) * om_sin_sign(5.0f * hit->p.y) * om_sin_sign(5.0f * hit->p.z);
+        scatter_lambertian(T, hit, (sines < 0) ? m->desc1 : m->desc2, st, out_ray, atten);
         return;
     }
     default: {  /* scatterMissingMaterial wgsl:309-314 */

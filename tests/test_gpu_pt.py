@@ -35,8 +35,12 @@ def test_pt_goldens(gpu_ctx, name):
                                             ("main_rs_scene", 128, 72, 70), ("rtiow_final", 64, 36, 4),
                                             ("three_spheres", 1, 1, 1), ("three_spheres", 3, 1, 64), ("earth", 1, 5, 65)])
 @pytest.mark.parametrize("flags", [0, LINEAR])
-def test_pt_vs_oracle_images_and_counters(gpu_ctx, oracle, scene, w, h, spp, flags):
+@pytest.mark.parametrize("kernel", [m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
+def test_pt_vs_oracle_images_and_counters(gpu_ctx, oracle, scene, w, h, spp, flags, kernel):
+    """Both schedules of the path-traced kernel (strip: wave = 64 samples of a pixel; pool: paths
+    sorted by material in LDS) must give the oracle's image and the oracle's work counters."""
     sd = scene_data(scene, w, h)
+    flags |= kernel
     p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags | m.MIRT_FLAG_COUNT_WORK)
     got = _render(gpu_ctx, sd, p)
     gs = gpu_ctx.stats()
@@ -50,12 +54,70 @@ def test_pt_vs_oracle_images_and_counters(gpu_ctx, oracle, scene, w, h, spp, fla
     assert_images_equal(gpu_ctx.render(p2), want, "plain build")
 
 
-@pytest.mark.parametrize("bounces", [0, 1, 2, 4, 10])
-def test_bounce_limits(gpu_ctx, oracle, bounces):
+@pytest.mark.parametrize("bounces", [0, 1, 2, 4, 10, 300])
+@pytest.mark.parametrize("kernel", [m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
+def test_bounce_limits(gpu_ctx, oracle, bounces, kernel):
+    """num_bounces = 300 exceeds the pool kernel's 8-bit bounce counter: the library must fall back
+    to the strip kernel by itself."""
     w, h = 64, 48
     sd = scene_data("main_rs_scene", w, h)
-    p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=LINEAR)
-    assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), f"bounces={bounces}")
+    p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=LINEAR | kernel | m.MIRT_FLAG_COUNT_WORK)
+    got = _render(gpu_ctx, sd, p)
+    gs = gpu_ctx.stats()
+    assert_images_equal(got, oracle.render(sd, p), f"bounces={bounces}")
+    os_ = oracle.stats()
+    assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+
+
+def test_one_by_one_texture_edge_cases(gpu_ctx, oracle):
+    """The exact shortcut for 1x1 textures (csrc albedo_at): a camera whose rays all lie in the plane
+    z = 0 hits the sphere with n.z == 0 exactly, so every left-hemisphere hit has atan2(-0, n.x<0) = pi,
+    u = 1.0, j = 1 and must read texel offset+1 (wgsl:377-387 quirk) — the guarded slow path."""
+    w, h = 256, 1
+    cam = m._abi.MirtGpuCamera()
+    cam.eye[:] = [0.0, 0.0, 0.0]
+    cam.horizontal[:] = [0.0, 4.0, 0.0]              # sweep in y only
+    cam.vertical[:] = [0.0, 0.0, 0.0]
+    cam.u[:] = [0.0, 1.0, 0.0]
+    cam.v[:] = [0.0, 0.0, 1.0]
+    cam.lens_radius = 0.0
+    cam.lower_left_corner[:] = [-3.0, -2.0, 0.0]     # looking down -x
+    mats, tex = m.flatten_materials([m.Material.Lambertian(m.Texture.new_from_color((0.9, 0.1, 0.1))),
+                                     m.Material.Lambertian(m.Texture.new_from_color((0.1, 0.9, 0.1)))])
+    # sphere straddling the view axis: hits have n.x of both signs? no: from the origin looking -x the
+    # visible cap has n.x > 0; put the eye INSIDE a big sphere instead so that n.x < 0 on the far side
+    spheres = [m.Sphere.new((0.0, 0.0, 0.0), 5.0, 0).to_c()]
+    sd = m.SceneData(cam, spheres, mats, tex)
+    for kernel in (m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL):
+        p = m.make_params(w, h, 64, mode=m.MIRT_MODE_PT, num_bounces=2, flags=LINEAR | kernel | m.MIRT_FLAG_COUNT_WORK)
+        got = _render(gpu_ctx, sd, p)
+        gs = gpu_ctx.stats()
+        want = oracle.render(sd, p)
+        assert_images_equal(got, want, "planar rays")
+        os_ = oracle.stats()
+        assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+    # the quirk is really exercised: blackening texel offset+1 changes the picture
+    tex2 = tex.copy()
+    tex2[1] = 0.0
+    sd2 = m.SceneData(cam, spheres, mats, tex2)
+    p = m.make_params(w, h, 64, mode=m.MIRT_MODE_PT, num_bounces=2, flags=LINEAR)
+    assert (oracle.render(sd2, p) != oracle.render(sd, p)).any()
+    assert_images_equal(_render(gpu_ctx, sd2, p), oracle.render(sd2, p), "planar rays, texel+1 changed")
+    # south-pole hits (n.y == -1): straight-down rays through the centre of a sphere below the eye
+    cam2 = m._abi.MirtGpuCamera()
+    cam2.eye[:] = [0.0, 3.0, 0.0]
+    cam2.horizontal[:] = [0.0, 0.0, 0.0]
+    cam2.vertical[:] = [0.0, 0.0, 0.0]
+    cam2.u[:] = [1.0, 0.0, 0.0]
+    cam2.v[:] = [0.0, 0.0, 1.0]
+    cam2.lower_left_corner[:] = [0.0, 13.0, 0.0]      # direction (0, +10, 0): hits the top... of an enclosing sphere
+    sd3 = m.SceneData(cam2, [m.Sphere.new((0.0, 3.0, 0.0), 4.0, 0).to_c()], mats, tex)
+    cam3 = m._abi.MirtGpuCamera.from_buffer_copy(bytes(cam2))
+    cam3.lower_left_corner[:] = [0.0, -7.0, 0.0]      # direction (0, -10, 0): hit normal (0,-1,0) exactly
+    sd4 = m.SceneData(cam3, [m.Sphere.new((0.0, 3.0, 0.0), 4.0, 0).to_c()], mats, tex)
+    for sdx in (sd3, sd4):
+        p = m.make_params(4, 4, 64, mode=m.MIRT_MODE_PT, num_bounces=3, flags=LINEAR)
+        assert_images_equal(_render(gpu_ctx, sdx, p), oracle.render(sdx, p), "polar hits")
 
 
 @pytest.mark.parametrize("seed", [1, 0xFFFFFFFF, 0x123456789ABCDEF0])

@@ -83,14 +83,22 @@ def main() -> int:
     w, h = 1920, 1080
     sd = scene_data("three_spheres", w, h)
     ctx.set_scene(sd)
-    for spp in ([10, 100, 1000] if args.full else [10, 100]):
-        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
-        t0 = time.time()
-        img = ctx.render(p)
-        wall = time.time() - t0
-        st = ctx.stats()
-        print(f"  spp={spp}: kernel {st['kernel_ms']:.2f} ms, wall {wall * 1e3:.1f} ms, "
-              f"{w * h * spp / st['kernel_ms'] / 1e3:.1f} Msamples/s, mean rgb {img[..., :3].reshape(-1, 3).mean(0)}", flush=True)
+    ref = None
+    for spp in ([100, 1000] if args.full else [100]):
+        for name, kflag in (("strip", m.MIRT_FLAG_KERNEL_STRIP), ("pool", m.MIRT_FLAG_KERNEL_POOL)):
+            p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=kflag)
+            ctx.render(p)
+            img = ctx.render(p)
+            st = ctx.stats()
+            p.flags |= m.MIRT_FLAG_COUNT_WORK
+            ctx.render(p)
+            sc = ctx.stats()
+            print(f"  spp={spp} {name}: kernel {st['kernel_ms']:.2f} ms, {w * h * spp / st['kernel_ms'] / 1e3:.1f} Msamples/s, "
+                  f"lane-util {sc['lane_iterations'] / max(1, 64 * sc['wave_iterations']):.3f}, mean rgb {img[..., :3].reshape(-1, 3).mean(0)}", flush=True)
+            if name == "strip":
+                ref = img
+            else:
+                ok &= compare(f"pool vs strip 1080p spp{spp}", img, ref)
     print("== timing: parity Layer::scene 1920x1080 ==", flush=True)
     sd = layer_scene_data(w, h)
     ctx.set_scene(sd)

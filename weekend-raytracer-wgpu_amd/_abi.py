@@ -14,6 +14,8 @@ MIRT_FLAG_SKY_HOSEK = 1 << 0
 MIRT_FLAG_NO_TONEMAP = 1 << 1
 MIRT_FLAG_NO_SRGB = 1 << 2
 MIRT_FLAG_COUNT_WORK = 1 << 3
+MIRT_FLAG_KERNEL_STRIP = 1 << 4
+MIRT_FLAG_KERNEL_POOL = 1 << 5
 
 MIRT_OK = 0
 STATUS = {

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -107,6 +108,7 @@ int ensure_capacity(T** ptr, size_t* cap, size_t need)
 struct MirtContext {
     int         device = -1;
     int         cu_count = 0;
+    size_t      lds_per_block = 65536, lds_per_cu = 65536;
     hipStream_t stream = nullptr;
     // hipEvent pairs around every render kernel, recorded on the stream the kernel runs on;
     // drained (summed) by mirt_ctx_get_stats so that no host sync sits inside a timed loop.
@@ -127,6 +129,8 @@ struct MirtContext {
     MirtGpuCamera*        d_cam = nullptr;
     mirt::PreparedSphere* d_spheres = nullptr;
     MirtMaterial*         d_mats = nullptr;
+    mirt::PreparedMaterial* d_pmats = nullptr;
+    size_t cap_pmats = 0;
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;
     size_t cap_spheres = 0, cap_mats = 0, cap_texels = 0;
@@ -284,6 +288,8 @@ int mirt_ctx_create(int device, MirtContext** out)
         return rc;
     }
     c->cu_count = prop.multiProcessorCount;
+    c->lds_per_block = prop.sharedMemPerBlock;            // 160 KiB on gfx950
+    c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
     *out = c;
     return MIRT_OK;
 }
@@ -293,7 +299,7 @@ void mirt_ctx_destroy(MirtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_texels);
+    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
@@ -307,7 +313,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_spheres && !s->spheres) return fail(MIRT_ERR_NULL_POINTER, "spheres is null");
     if (s->n_materials && !s->materials) return fail(MIRT_ERR_NULL_POINTER, "materials is null");
     if (s->n_texels && !s->texels) return fail(MIRT_ERR_NULL_POINTER, "texels is null");
-    if (mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true) > mirt::kMaxLdsBytes)
+    if (mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) > mirt::kMaxLdsBytes)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
                     s->n_materials, mirt::kMaxLdsBytes);
     HIP_TRY(hipSetDevice(c->device));
@@ -338,7 +344,33 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         o.material_idx = in.material_idx;
         o._pad = 0;
     }
+    // PreparedMaterial: GpuMaterial + 1/x + the texel of every 1x1 texture (see mirt_kernels.h)
+    std::vector<mirt::PreparedMaterial> pmats(s->n_materials);
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const MirtMaterial& in = s->materials[i];
+        mirt::PreparedMaterial& o = pmats[i];
+        std::memset(&o, 0, sizeof o);
+        o.id = in.id;
+        o.x = in.x;
+        o.inv_x = 1.0f / in.x;
+        const MirtTextureDescriptor* d[2] = { &in.desc1, &in.desc2 };
+        for (int k = 0; k < 2; ++k) {
+            uint32_t w = d[k]->width, h = d[k]->height, off = d[k]->offset;
+            if (w == 1 && h == 1 && (uint64_t)off < s->n_texels) {
+                o.flags |= (1u << k);
+                o.tex[k][0] = s->texels[3 * (size_t)off + 0];
+                o.tex[k][1] = s->texels[3 * (size_t)off + 1];
+                o.tex[k][2] = s->texels[3 * (size_t)off + 2];
+                std::memcpy(&o.tex[k][3], &off, 4);
+            } else {
+                std::memcpy(&o.tex[k][0], &w, 4);
+                std::memcpy(&o.tex[k][1], &h, 4);
+                std::memcpy(&o.tex[k][2], &off, 4);
+            }
+        }
+    }
     int rc;
+    if ((rc = ensure_capacity(&c->d_pmats, &c->cap_pmats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_spheres, &c->cap_spheres, (size_t)s->n_spheres)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_mats, &c->cap_mats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_texels, &c->cap_texels, (size_t)s->n_texels * 3)) != MIRT_OK) return rc;
@@ -346,6 +378,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     HIP_TRY(hipMemcpy(c->d_cam, s->camera, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
     if (s->n_spheres) HIP_TRY(hipMemcpy(c->d_spheres, prep.data(), prep.size() * sizeof(mirt::PreparedSphere), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
+    if (s->n_materials) HIP_TRY(hipMemcpy(c->d_pmats, pmats.data(), pmats.size() * sizeof(mirt::PreparedMaterial), hipMemcpyHostToDevice));
     if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
     c->have_sky = s->sky != nullptr;
     if (s->sky) HIP_TRY(hipMemcpy(c->d_sky, s->sky, sizeof(MirtSkyState), hipMemcpyHostToDevice));
@@ -414,8 +447,23 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool count = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_COUNT_WORK);
     const bool hosek = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_SKY_HOSEK);
 
+    const bool pt = p->mode == MIRT_MODE_PT;
+    const size_t scene_lds = mirt::scene_lds_bytes(c->n_spheres, c->n_mats, pt, hosek);
+    // kernel choice (path-traced mode): the pooled kernel needs enough samples per tile to keep
+    // its path pool full, 8-bit bounce counters and room for the pool beside the scene in LDS
+    bool pool = pt && p->spp >= mirt::kPoolMinSpp;
+    if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
+    if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
+    uint32_t pool_cfg = mirt::kDefaultPoolConfig;
+    if (const char* e = std::getenv("MIRT_POOL_CONFIG")) {          // tuning knob: geometry of the path pool
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) pool_cfg = (uint32_t)v;
+    }
+    const mirt::PoolConfig pc = mirt::pool_config(pool_cfg);
+    if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block) pool = false;
+
     mirt::RenderArgs a{};
-    a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.texels = c->d_texels; a.sky = c->d_sky;
+    a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
     a.out = d_out; a.counters = c->d_counters; a.work_counter = c->d_work_counter;
     a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
@@ -423,20 +471,33 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.sample_begin = p->sample_begin;
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
-    a.n_strips = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
-    a.lds_bytes = (uint32_t)mirt::scene_lds_bytes(c->n_spheres, c->n_mats, hosek);
+    a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
+    a.lds_bytes = (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
 
-    const uint32_t waves_per_block = mirt::kBlockThreads / 64;
-    uint32_t blocks = (a.n_strips + waves_per_block - 1) / waves_per_block;
-    const uint32_t resident = (uint32_t)c->cu_count * 8u;     // 2048 threads per CU / 256
-    if (blocks > resident) blocks = resident;
+    uint32_t blocks;
+    if (pool) {
+        uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
+        const uint32_t by_waves = 20u / (pc.threads / 64u);   // ~95 VGPRs -> 5 waves per SIMD = 20 per CU
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu == 0u) per_cu = 1u;
+        blocks = (uint32_t)c->cu_count * per_cu;
+        const uint32_t units_per_block = pc.threads / 64u;
+        const uint32_t need = (a.n_units + units_per_block - 1) / units_per_block;
+        if (blocks > need) blocks = need;
+    } else {
+        const uint32_t waves_per_block = mirt::kBlockThreads / 64;
+        blocks = (a.n_units + waves_per_block - 1) / waves_per_block;
+        const uint32_t resident = (uint32_t)c->cu_count * 8u;     // 2048 threads per CU / 256
+        if (blocks > resident) blocks = resident;
+    }
     if (blocks == 0) blocks = 1;
 
     HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), stream));
     if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
-    else HIP_TRY(mirt::launch_pt(a, blocks, count, stream));
+    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, stream));
+    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     c->ev_used = ev + 1;
     c->stats_counted = count;

@@ -70,6 +70,23 @@ MIRT_DEV SinCos sincos_(float x)
     return o;
 }
 
+// Sign of sin(x) in {-1, 0, +1}: the argument reduction of sincos_ without the polynomials.
+// For |r| <= pi/4 cos(r) > 0 and sin(r) has the sign of r (zero iff r == 0).
+MIRT_DEV int sin_sign(float x)
+{
+    constexpr float kTwoOverPi = 0.63661975f, kMagic = 12582912.0f;
+    constexpr float kHi = 1.5703125f, kMd = 4.837512969970703125e-4f, kLo = 7.54978995489188216e-8f;
+    x = (abs_(x) <= 1048576.0f) ? x : 0.0f;
+    const float kf = (x * kTwoOverPi + kMagic) - kMagic;
+    const int q = (int)kf;
+    float r = fma_(-kf, kHi, x);
+    r = fma_(-kf, kMd, r);
+    r = fma_(-kf, kLo, r);
+    const int sr = (r > 0.0f) - (r < 0.0f);
+    const int base = (q & 1) ? 1 : sr;
+    return (q & 2) ? -base : base;
+}
+
 MIRT_DEV float asin_core(float x, float z)
 {
     constexpr float kAsin[6] = { 0x1.5555540000000p-3f, 0x1.3334300000000p-4f, 0x1.6d5bba0000000p-5f, 0x1.fd8da20000000p-6f, 0x1.18f91e0000000p-6f, 0x1.13fed40000000p-5f };

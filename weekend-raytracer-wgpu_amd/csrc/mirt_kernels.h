@@ -22,10 +22,29 @@ struct PreparedSphere {
 };
 static_assert(sizeof(PreparedSphere) == 32, "PreparedSphere must stay 2 x 16 B for ds_read_b128");
 
-constexpr uint32_t kStripPixels   = 16;   // pixels one wave owns per work unit -> one 64-B coalesced RGBA8 store
-constexpr uint32_t kBlockThreads  = 256;  // 4 waves
+// A material as the path-traced kernels read it from LDS: `GpuMaterial` (mod.rs:757-765) plus
+// values derived once on the host: 1/x (the dielectric's `1f / refractionIndex`, wgsl:261) and,
+// for 1x1 textures (every colour material of the reference's scenes), the texel itself so that
+// the common lookup needs no global-memory access.
+//   tex[k] for a 1x1 texture: { r, g, b, bits(offset) };  otherwise { bits(w), bits(h), bits(offset), 0 }.
+struct PreparedMaterial {
+    uint32_t id;
+    float    x;
+    float    inv_x;
+    uint32_t flags;            // bit 0: desc1 is 1x1, bit 1: desc2 is 1x1
+    float    tex[2][4];
+};
+static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
+constexpr uint32_t kMatTex1Is1x1 = 1u, kMatTex2Is1x1 = 2u;
+
+constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
+constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
-constexpr uint32_t kMaxLdsBytes   = 64 * 1024;  // scene budget in LDS (2 blocks/CU stay resident)
+constexpr uint32_t kMaxLdsBytes   = 64 * 1024;  // scene budget in LDS
+
+// pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
+constexpr uint32_t kDefaultPoolConfig = 0;
+constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cannot keep the pool full: strip kernel
 
 enum CounterSlot : uint32_t {
     kCntRays = 0, kCntTests, kCntRoots, kCntHits,
@@ -34,20 +53,21 @@ enum CounterSlot : uint32_t {
 };
 
 struct RenderArgs {
-    const MirtGpuCamera*  cam;
-    const PreparedSphere* spheres;
-    const MirtMaterial*   mats;
-    const float*          texels;
-    const MirtSkyState*   sky;
-    uint32_t*             out;           // compact RGBA8, one u32 per pixel
-    unsigned long long*   counters;      // [kNumCounters], COUNT builds only
-    uint32_t*             work_counter;  // dynamic strip dispenser, zeroed before every launch
-    uint64_t              n_texels;
+    const MirtGpuCamera*    cam;
+    const PreparedSphere*   spheres;
+    const MirtMaterial*     mats;          // reference layout (parity kernel)
+    const PreparedMaterial* pmats;         // derived layout (path-traced kernels)
+    const float*            texels;
+    const MirtSkyState*     sky;
+    uint32_t*               out;           // compact RGBA8, one u32 per pixel
+    unsigned long long*     counters;      // [kNumCounters], COUNT builds only
+    uint32_t*               work_counter;  // dynamic work dispenser, zeroed before every launch
+    uint64_t                n_texels;
     uint32_t n_spheres, n_mats;
     uint32_t width, height, spp, num_bounces, flags, seed_mix, sample_begin;
     uint32_t row_begin, tile_rows, n_parts, part;
-    uint32_t out_rows;                   // rows this launch writes
-    uint32_t n_strips;                   // ceil(out_rows*width / kStripPixels)
+    uint32_t out_rows;                     // rows this launch writes
+    uint32_t n_units;                      // work units: strips (strip kernels) or tiles (pool kernel)
     uint32_t lds_bytes;
 };
 
@@ -60,8 +80,12 @@ struct DeinterleaveArgs {
 
 // launchers (mirt_kernels.hip)
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream);
-hipError_t launch_pt(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
+struct PoolConfig { uint32_t threads, slots, lds_bytes; };
+uint32_t   pool_config_count();
+PoolConfig pool_config(uint32_t i);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream);
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream);
-size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool hosek);
+size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek);
 
 }  // namespace mirt

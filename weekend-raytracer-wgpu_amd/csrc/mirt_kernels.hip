@@ -1,15 +1,20 @@
 // mirt_kernels.hip — the gfx950 (CDNA4, wave64) kernels of the per-pixel ray-trace path.
 //
-// Work decomposition (both kernels): ONE WORKITEM PER PIXEL-SAMPLE.  A wave owns a strip of
-// kStripPixels consecutive pixels; for each pixel its 64 lanes take samples s = lane, lane+64, …
-// so a wave-instruction advances 64 samples of one pixel.  Strips are handed out by a global
-// atomic dispenser (cost per pixel varies 10x between sky and glass).  The scene (camera, sphere
-// list, material table) is staged once per block into LDS; all lanes read the same sphere at the
-// same time, which LDS serves as a broadcast.  Wave ballots give the uniform loop exits.  Each
-// wave finishes its strip with one coalesced 64-byte RGBA8 store.
+// ONE WORKITEM PER PIXEL-SAMPLE everywhere.  The scene (camera, sphere list, material table) is
+// staged once per block into LDS; all lanes read the same sphere at the same time, which LDS
+// serves as a broadcast.  Wave ballots give the uniform loop exits and resolve the sequential
+// semantics of the reference's sample loop.
 //
-//   render_parity : reference src/raytracer/layer.rs:264-444 semantics, bit-faithful (no fma).
-//   render_pt     : behaviours of reference src/raytracer/raytracer.wgsl:50-521 (explicit fma).
+//   render_parity_kernel   reference src/raytracer/layer.rs:264-444 semantics, bit-faithful, no fma.
+//   render_pt_strip_kernel behaviours of src/raytracer/raytracer.wgsl:50-521; a wave owns a strip of
+//                          pixels, its 64 lanes take samples lane, lane+64, …  (small spp, huge scenes).
+//   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
+//                          paths in LDS, queued by the shading routine they wait for, and always
+//                          runs ONE routine on up to 64 of them — the material switch no longer
+//                          serialises inside a wave (default for spp >= 48).
+//
+// Every pixel's radiance is summed in 64-bit fixed point (exact, order-independent), so the three
+// schedules — and any GPU count — give bit-identical images.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add in this file is an explicit fma_().
 #include "mirt_kernels.h"
@@ -22,25 +27,28 @@ namespace mirt {
 // ------------------------------------------------------------------------------------------
 
 struct SceneLds {
-    const float*          cam;      // 24 floats, MirtGpuCamera layout
-    const PreparedSphere* spheres;
-    const MirtMaterial*   mats;
-    const float*          sky;      // 36 floats (MirtSkyState) or nullptr
+    const float*            cam;      // 24 floats, MirtGpuCamera layout
+    const PreparedSphere*   spheres;
+    const MirtMaterial*     mats;     // parity kernel
+    const PreparedMaterial* pmats;    // path-traced kernels
+    const float*            sky;      // 36 floats (MirtSkyState) or nullptr
+    unsigned char*          end;      // first byte after the staged scene (16-B aligned)
 };
 
-MIRT_DEV size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
-
 // Cooperative global -> LDS copy of the scene tables, 16 B per thread per step.
+// PT = false stages the reference-layout material table, PT = true the prepared one.
+template <bool PT>
 MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hosek)
 {
+    constexpr uint32_t kMatQuads = PT ? sizeof(PreparedMaterial) / 16 : sizeof(MirtMaterial) / 16;
     const uint32_t n_cam = sizeof(MirtGpuCamera) / 16;
     const uint32_t n_sph = A.n_spheres * 2;
-    const uint32_t n_mat = A.n_mats * 2;
+    const uint32_t n_mat = A.n_mats * kMatQuads;
     const uint32_t n_sky = hosek ? sizeof(MirtSkyState) / 16 : 0;
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const uint4* src_cam = reinterpret_cast<const uint4*>(A.cam);
     const uint4* src_sph = reinterpret_cast<const uint4*>(A.spheres);
-    const uint4* src_mat = reinterpret_cast<const uint4*>(A.mats);
+    const uint4* src_mat = PT ? reinterpret_cast<const uint4*>(A.pmats) : reinterpret_cast<const uint4*>(A.mats);
     const uint4* src_sky = reinterpret_cast<const uint4*>(A.sky);
     const uint32_t total = n_cam + n_sph + n_mat + n_sky;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
@@ -56,8 +64,16 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     S.cam = reinterpret_cast<const float*>(smem);
     S.spheres = reinterpret_cast<const PreparedSphere*>(smem + 16 * n_cam);
     S.mats = reinterpret_cast<const MirtMaterial*>(smem + 16 * (n_cam + n_sph));
+    S.pmats = reinterpret_cast<const PreparedMaterial*>(smem + 16 * (n_cam + n_sph));
     S.sky = hosek ? reinterpret_cast<const float*>(smem + 16 * (n_cam + n_sph + n_mat)) : nullptr;
+    S.end = smem + 16 * total;
     return S;
+}
+
+MIRT_DEV size_t scene_lds_bytes_dev(uint32_t n_spheres, uint32_t n_mats, bool hosek)
+{
+    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) + (size_t)n_mats * sizeof(PreparedMaterial) +
+           (hosek ? sizeof(MirtSkyState) : 0);
 }
 
 // compact output row -> absolute image row (MirtParams contract, include/mirt.h)
@@ -68,7 +84,7 @@ MIRT_DEV uint32_t abs_row(const RenderArgs& A, uint32_t i)
     return A.row_begin + t * A.tile_rows + i % A.tile_rows;
 }
 
-MIRT_DEV uint32_t next_strip(const RenderArgs& A, uint32_t lane)
+MIRT_DEV uint32_t next_unit(const RenderArgs& A, uint32_t lane)
 {
     uint32_t s = 0;
     if (lane == 0) s = atomicAdd(A.work_counter, 1u);
@@ -91,18 +107,22 @@ MIRT_DEV uint32_t sat_u8(float f)    // Rust `as u8` (math.rs:15-17)
 
 MIRT_DEV float clamp01(float x) { return (x < 0.0f) ? 0.0f : ((x > 1.0f) ? 1.0f : x); }
 
-// texture_lookup (mod.rs:1000-1019 == wgsl:377-387); final index clamped to the table.
-MIRT_DEV f3 texture_lookup(const RenderArgs& A, const MirtTextureDescriptor d, float u, float v)
+MIRT_DEV f3 texel_at(const RenderArgs& A, uint64_t g)
 {
-    const float uc = clamp01(u);
-    const float vf = 1.0f - clamp01(v);
-    const uint32_t j = sat_u32(uc * (float)d.width);
-    const uint32_t i = sat_u32(vf * (float)d.height);
-    const uint32_t idx = i * d.width + j;
-    uint64_t g = (uint64_t)d.offset + (uint64_t)idx;
     if (g >= A.n_texels) g = A.n_texels - 1;
     const float* e = A.texels + 3 * g;
     return mk(e[0], e[1], e[2]);
+}
+
+// texture_lookup (mod.rs:1000-1019 == wgsl:377-387); final index clamped to the table.
+MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height, uint32_t offset, float u, float v)
+{
+    const float uc = clamp01(u);
+    const float vf = 1.0f - clamp01(v);
+    const uint32_t j = sat_u32(uc * (float)width);
+    const uint32_t i = sat_u32(vf * (float)height);
+    const uint32_t idx = i * width + j;
+    return texel_at(A, (uint64_t)offset + (uint64_t)idx);
 }
 
 MIRT_DEV unsigned long long wave_sum_u64(unsigned long long v)
@@ -161,7 +181,7 @@ MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay
 __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SceneLds S = stage_scene(A, smem, false);
+    const SceneLds S = stage_scene<false>(A, smem, false);
     const uint32_t lane = threadIdx.x & 63u;
     const float wf = (float)A.width, hf = (float)A.height;
     const uint32_t npix = A.out_rows * A.width;
@@ -173,8 +193,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
     const f3 llc = mk(S.cam[20], S.cam[21], S.cam[22]);
 
     for (;;) {
-        const uint32_t strip = next_strip(A, lane);
-        if (strip >= A.n_strips) break;
+        const uint32_t strip = next_unit(A, lane);
+        if (strip >= A.n_units) break;
         const uint32_t base = strip * kStripPixels;
         uint32_t my_px = 0;
         for (uint32_t p = 0; p < kStripPixels; ++p) {
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
                     // material hard-wired to index 2; texture looked up with SCREEN-space (uu,vv) (layer.rs:345-351)
                     const MirtMaterial m2 = S.mats[2];
                     const float fuzzy = m2.x;
-                    const f3 albedo = texture_lookup(A, m2.desc1, uu, vv);
+                    const f3 albedo = texture_lookup(A, m2.desc1.width, m2.desc1.height, m2.desc1.offset, uu, vv);
                     // scatter_metal mod.rs:1292-1315; unit_vertor divides by 3 (math.rs:147-149)
                     const f3 unit = mk(ray.d.x / 3.0f, ray.d.y / 3.0f, ray.d.z / 3.0f);
                     const float k = 2.0f * dot_nofma(unit, rec.n);      // reflect math.rs:154-159
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
 }
 
 // ------------------------------------------------------------------------------------------
-// render_pt — WGSL behaviours, one (pixel, sample) per lane
+// path-traced mode: building blocks shared by the strip and the pool kernel
 // ------------------------------------------------------------------------------------------
 
 MIRT_DEV uint32_t jenkins_hash(uint32_t x)
@@ -290,6 +310,76 @@ struct Work {
     }
 };
 
+// camera constants hoisted into registers once per thread
+struct CamRegs {
+    f3 eye, hor, ver, cam_u, cam_v, llc;
+    float lens_radius, inv_w, inv_h;
+};
+
+MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
+{
+    CamRegs c;
+    c.eye = mk(S.cam[0], S.cam[1], S.cam[2]);
+    c.hor = mk(S.cam[4], S.cam[5], S.cam[6]);
+    c.ver = mk(S.cam[8], S.cam[9], S.cam[10]);
+    c.cam_u = mk(S.cam[12], S.cam[13], S.cam[14]);
+    c.cam_v = mk(S.cam[16], S.cam[17], S.cam[18]);
+    c.lens_radius = S.cam[19];
+    c.llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    c.inv_w = 1.0f / (float)A.width;
+    c.inv_h = 1.0f / (float)A.height;
+    return c;
+}
+
+// initRng (wgsl:498-502, frame = sample + 1) + samplePixel (wgsl:114-117) + cameraMakeRay (wgsl:456-478)
+MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x, uint32_t y, uint32_t sample,
+                               Rng& rng, f3& ro, f3& rd)
+{
+    const uint32_t pixel_index = x + y * A.width;
+    rng.state = jenkins_hash((pixel_index ^ jenkins_hash(sample + 1u)) ^ A.seed_mix);
+    const float u = ((float)x + rng.next()) * C.inv_w;
+    const float v = 1.0f - ((float)y + rng.next()) * C.inv_h;
+    const float lr = sqrt_(rng.next());
+    const SinCos la = sincos_(kTwoPi * rng.next());
+    const float lpx = C.lens_radius * (lr * la.c);
+    const float lpy = C.lens_radius * (lr * la.s);
+    ro = C.eye + fma3(lpy, C.cam_v, lpx * C.cam_u);
+    rd = fma3(v, C.ver, fma3(u, C.hor, C.llc)) - ro;
+}
+
+// nearest hit (wgsl:135-145, 407-429): every lane walks the same sphere list in LDS
+template <bool COUNT>
+MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bool alive, float& closest_out,
+                         Work<COUNT>& work)
+{
+    const float a = dot(rd, rd);
+    const float inv_a = 1.0f / a;
+    float closest = kMaxT;
+    int best = -1;
+    if (alive) { work.add(kCntRays); work.add(kCntTests, n_spheres); }
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
+        const f3 oc = ro - mk(s4.x, s4.y, s4.z);
+        const float b = dot(oc, rd);
+        const float cq = dot(oc, oc) - s4.w;
+        const float disc = fma_(b, b, -(a * cq));
+        if (alive && disc > 0.0f) {
+            const float sq = sqrt_(disc);
+            float t = (-b - sq) * inv_a;
+            bool ok = (t < closest) && (t > kMinT);
+            work.add(kCntRoots);
+            if (!ok) {
+                t = (-b + sq) * inv_a;
+                ok = (t < closest) && (t > kMinT);
+                work.add(kCntRoots);
+            }
+            if (ok) { closest = t; best = (int)i; }
+        }
+    }
+    closest_out = closest;
+    return best;
+}
+
 MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
 {
     const float r = pow_pos(rng.next(), 0.33333f);
@@ -304,20 +394,36 @@ MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 
 MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
 
-struct HitUV { float u, v; };
-MIRT_DEV HitUV sphere_uv(f3 n)               // wgsl:434-437
+// Albedo of texture k of a material at a hit with outward normal n: sphereIntersection's (u,v)
+// (wgsl:434-437) fed to textureLookup (wgsl:377-387).
+// 1x1 textures — every colour material in the reference's scenes — take a shortcut that is
+// EXACT: the lookup returns texel `offset` unless u rounds to 1.0 (j = 1) or 1-v rounds to 1.0
+// (i = 1).  u = phi/(2pi) reaches 1.0 only for atan2(-n.z, n.x) within ~4e-7 of +pi, i.e.
+// n.x < 0 and |n.z| <= ~5e-7 |n.x|; 1-v reaches 1.0 only for acos(-n.y) < 1e-7, i.e. n.y <= -1.
+// The guards below are 20x / 1e-6 wider than that (and false for NaN), and the rare lanes they
+// catch run the full formula.
+MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n)
 {
+    const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[k][0]);    // one ds_read_b128 (m lives in LDS)
+    const float t[4] = { t4.x, t4.y, t4.z, t4.w };
+    const bool one = (m->flags >> k) & 1u;
+    if (one) {
+        const bool safe_v = n.y > -0.999999f;
+        const bool safe_u = (n.x >= 0.0f) || (abs_(n.z) > 1.0e-5f * abs_(n.x));
+        if (safe_u && safe_v) return mk(t[0], t[1], t[2]);
+    }
     const float theta = acos_(-n.y);
     const float phi = atan2_(-n.z, n.x) + kPi;
-    HitUV r;
-    r.u = (0.5f * kFrac1Pi) * phi;
-    r.v = kFrac1Pi * theta;
-    return r;
+    const float u = (0.5f * kFrac1Pi) * phi;
+    const float v = kFrac1Pi * theta;
+    const uint32_t w = one ? 1u : bits(t[0]);
+    const uint32_t h = one ? 1u : bits(t[1]);
+    const uint32_t off = one ? bits(t[3]) : bits(t[2]);
+    return texture_lookup(A, w, h, off, u, v);
 }
 
 // scatterLambertian (wgsl:204-242): cosine-weighted direction around n through the Pixar ONB
-MIRT_DEV void scatter_lambertian(const RenderArgs& A, const MirtTextureDescriptor tex, f3 n, HitUV uv, Rng& rng,
-                                 f3& dir, f3& atten)
+MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, Rng& rng, f3& dir, f3& atten)
 {
     const float r1 = rng.next();
     const float r2 = rng.next();
@@ -333,9 +439,61 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const MirtTextureDescripto
     const f3 V = mk(bb, fma_(n.y, n.y * aa, sg), -n.y);
     const f3 wi = fma3(z, n, fma3(ly, V, lx * U));
     const float dn = dot(n, wi);
-    const float k = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dn * kFrac1Pi);
-    atten = k * texture_lookup(A, tex, uv.u, uv.v);
+    // eval/pdf (wgsl:206): (FRAC_1_PI*max(eps,dn)) / max(eps, dn*FRAC_1_PI).  When dn*FRAC_1_PI > eps both
+    // max() pick their second argument and the quotient is x/x = 1 exactly; only grazing directions divide.
+    const float dnc = dn * kFrac1Pi;
+    float kk = 1.0f;
+    if (!(dnc > kEpsilon)) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
+    atten = kk * albedo_at(A, m, k, n);
     dir = wi;
+}
+
+// The five scatter routines of scatterRay (wgsl:174-314), one function each so that the pool
+// kernel can run exactly one of them per wave.  rd = incoming direction, hp/hn = hit point/normal.
+MIRT_DEV void shade_lambertian(const RenderArgs& A, const PreparedMaterial* m, f3 hn, Rng& rng, f3& ndir, f3& att)
+{
+    scatter_lambertian(A, m, 0, hn, rng, ndir, att);
+}
+
+MIRT_DEV void shade_metal(const RenderArgs& A, const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
+{   // scatterMetal wgsl:244-248
+    const f3 refl = reflect3(rd, hn);
+    const f3 rs = rand_in_unit_sphere(rng);
+    ndir = fma3(m->x, rs, refl);
+    att = albedo_at(A, m, 0, hn);
+}
+
+MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
+{   // scatterDielectric wgsl:250-292; the Schlick draw is consumed and the reflection discarded (wgsl:266-273)
+    const float dn = dot(rd, hn);
+    const f3 uvn = normalize(rd);
+    const bool inside = dn > 0.0f;
+    const f3 outn = inside ? -hn : hn;
+    const float ratio = inside ? m->x : m->inv_x;
+    const float dt = dot(uvn, outn);
+    const float disc = fma_(-(ratio * ratio), fma_(-dt, dt, 1.0f), 1.0f);
+    if (disc > 0.0f) {
+        const float sq = sqrt_(disc);
+        const f3 q = fma3(-dt, outn, uvn);
+        ndir = normalize(fma3(-sq, outn, ratio * q));
+        (void)rng.next();
+    } else {
+        ndir = reflect3(rd, hn);
+    }
+    att = mk(1, 1, 1);
+}
+
+MIRT_DEV void shade_checkerboard(const RenderArgs& A, const PreparedMaterial* m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att)
+{   // scatterCheckerboard wgsl:300-307: sign of sin(5x)sin(5y)sin(5z) from the signs of the factors
+    const int sines = sin_sign(5.0f * hp.x) * sin_sign(5.0f * hp.y) * sin_sign(5.0f * hp.z);
+    scatter_lambertian(A, m, (sines < 0) ? 0 : 1, hn, rng, ndir, att);
+}
+
+MIRT_DEV void shade_missing(f3 hn, Rng& rng, f3& ndir, f3& att)
+{   // scatterMissingMaterial wgsl:309-314
+    const f3 rs = rand_in_unit_sphere(rng);
+    ndir = hn + rs;
+    att = mk(0.9921f, 0.24705f, 0.57254f);
 }
 
 // radiance() wgsl:316-343, one channel of the Hosek-Wilkie state held in LDS
@@ -405,30 +563,25 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
     return (uint32_t)fma_(m, 255.0f, 0.5f);
 }
 
+// ------------------------------------------------------------------------------------------
+// render_pt_strip — lane = sample of one pixel, per-lane material switch
+// ------------------------------------------------------------------------------------------
+
 template <bool COUNT, bool HOSEK>
-__global__ __launch_bounds__(kBlockThreads) void render_pt_kernel(RenderArgs A)
+__global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SceneLds S = stage_scene(A, smem, HOSEK);
+    const SceneLds S = stage_scene<true>(A, smem, HOSEK);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t npix = A.out_rows * A.width;
-    const float inv_w = 1.0f / (float)A.width;
-    const float inv_h = 1.0f / (float)A.height;
-
-    const f3 eye = mk(S.cam[0], S.cam[1], S.cam[2]);
-    const f3 hor = mk(S.cam[4], S.cam[5], S.cam[6]);
-    const f3 ver = mk(S.cam[8], S.cam[9], S.cam[10]);
-    const f3 cam_u = mk(S.cam[12], S.cam[13], S.cam[14]);
-    const f3 cam_v = mk(S.cam[16], S.cam[17], S.cam[18]);
-    const float lens_radius = S.cam[19];
-    const f3 llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    const CamRegs C = load_camera(S, A);
 
     Work<COUNT> work;
     work.clear();
 
     for (;;) {
-        const uint32_t strip = next_strip(A, lane);
-        if (strip >= A.n_strips) break;
+        const uint32_t strip = next_unit(A, lane);
+        if (strip >= A.n_units) break;
         const uint32_t base = strip * kStripPixels;
         uint32_t my_px = 0;
         for (uint32_t p = 0; p < kStripPixels; ++p) {
@@ -437,60 +590,26 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_kernel(RenderArgs A)
             const uint32_t ci = pi / A.width;
             const uint32_t x = pi - ci * A.width;
             const uint32_t y = abs_row(A, ci);
-            const uint32_t pixel_index = x + y * A.width;
 
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
             for (uint32_t s0 = 0; s0 < A.spp; s0 += 64) {
                 const uint32_t s = s0 + lane;
                 bool alive = s < A.spp;
-                // initRng wgsl:498-502 with frame = sample + 1
                 Rng rng;
-                rng.state = jenkins_hash((pixel_index ^ jenkins_hash(A.sample_begin + s + 1u)) ^ A.seed_mix);
-                // samplePixel wgsl:114-117
-                const float u = ((float)x + rng.next()) * inv_w;
-                const float v = 1.0f - ((float)y + rng.next()) * inv_h;
-                // cameraMakeRay wgsl:456-478
-                const float lr = sqrt_(rng.next());
-                const SinCos la = sincos_(kTwoPi * rng.next());
-                const float lpx = lens_radius * (lr * la.c);
-                const float lpy = lens_radius * (lr * la.s);
-                f3 ro = eye + fma3(lpy, cam_v, lpx * cam_u);
-                f3 rd = fma3(v, ver, fma3(u, hor, llc)) - ro;
+                f3 ro, rd;
+                generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
                 f3 thr = mk(1, 1, 1);
                 f3 color = mk(0, 0, 0);
 
                 // rayColor wgsl:124-172
                 for (uint32_t bounce = 0; bounce < A.num_bounces; ++bounce) {
-                    const unsigned long long alive_mask = __ballot(alive);
-                    if (!alive_mask) break;
+                    if (!__ballot(alive)) break;
                     if constexpr (COUNT) {
                         if (lane == 0) work.add(kCntWaveIters);
-                        if (alive) { work.add(kCntLaneIters); work.add(kCntRays); work.add(kCntTests, A.n_spheres); }
+                        if (alive) work.add(kCntLaneIters);
                     }
-                    // nearest hit (wgsl:135-145, 407-429): every lane walks the same sphere list in LDS
-                    const float a = dot(rd, rd);
-                    const float inv_a = 1.0f / a;
-                    float closest = kMaxT;
-                    int best = -1;
-                    for (uint32_t i = 0; i < A.n_spheres; ++i) {
-                        const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
-                        const f3 oc = ro - mk(s4.x, s4.y, s4.z);
-                        const float b = dot(oc, rd);
-                        const float cq = dot(oc, oc) - s4.w;
-                        const float disc = fma_(b, b, -(a * cq));
-                        if (alive && disc > 0.0f) {
-                            const float sq = sqrt_(disc);
-                            float t = (-b - sq) * inv_a;
-                            bool ok = (t < closest) && (t > kMinT);
-                            work.add(kCntRoots);
-                            if (!ok) {
-                                t = (-b + sq) * inv_a;
-                                ok = (t < closest) && (t > kMinT);
-                                work.add(kCntRoots);
-                            }
-                            if (ok) { closest = t; best = (int)i; }
-                        }
-                    }
+                    float closest;
+                    const int best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
                     if (alive) {
                         if (best >= 0) {
                             work.add(kCntHits);
@@ -498,59 +617,14 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_kernel(RenderArgs A)
                             const PreparedSphere sp = S.spheres[best];
                             const f3 hp = fma3(closest, rd, ro);
                             const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
-                            const MirtMaterial m = S.mats[sp.material_idx];
+                            const PreparedMaterial* m = &S.pmats[sp.material_idx];
                             f3 ndir, att;
-                            switch (m.id) {     // scatterRay wgsl:174-202
-                            case 0u: {
-                                work.add(kCntScatter0);
-                                scatter_lambertian(A, m.desc1, hn, sphere_uv(hn), rng, ndir, att);
-                                break;
-                            }
-                            case 1u: {          // scatterMetal wgsl:244-248
-                                work.add(kCntScatter1);
-                                const f3 refl = reflect3(rd, hn);
-                                const f3 rs = rand_in_unit_sphere(rng);
-                                ndir = fma3(m.x, rs, refl);
-                                const HitUV uv = sphere_uv(hn);
-                                att = texture_lookup(A, m.desc1, uv.u, uv.v);
-                                break;
-                            }
-                            case 2u: {          // scatterDielectric wgsl:250-292; always refracts when it can
-                                work.add(kCntScatter2);
-                                const float dn = dot(rd, hn);
-                                const f3 uvn = normalize(rd);
-                                const bool inside = dn > 0.0f;
-                                const f3 outn = inside ? -hn : hn;
-                                const float ratio = inside ? m.x : (1.0f / m.x);
-                                const float dt = dot(uvn, outn);
-                                const float disc = fma_(-(ratio * ratio), fma_(-dt, dt, 1.0f), 1.0f);
-                                if (disc > 0.0f) {
-                                    const float sq = sqrt_(disc);
-                                    const f3 q = fma3(-dt, outn, uvn);
-                                    ndir = normalize(fma3(-sq, outn, ratio * q));
-                                    (void)rng.next();          // the discarded Schlick draw (wgsl:269)
-                                } else {
-                                    ndir = reflect3(rd, hn);
-                                }
-                                att = mk(1, 1, 1);
-                                break;
-                            }
-                            case 3u: {          // scatterCheckerboard wgsl:300-307
-                                work.add(kCntScatter3);
-                                const float sx = sincos_(5.0f * hp.x).s, sy = sincos_(5.0f * hp.y).s,
-                                            sz = sincos_(5.0f * hp.z).s;
-                                const float sines = (sx * sy) * sz;
-                                scatter_lambertian(A, (sines < 0.0f) ? m.desc1 : m.desc2, hn, sphere_uv(hn), rng,
-                                                   ndir, att);
-                                break;
-                            }
-                            default: {          // scatterMissingMaterial wgsl:309-314
-                                work.add(kCntScatter4);
-                                const f3 rs = rand_in_unit_sphere(rng);
-                                ndir = hn + rs;
-                                att = mk(0.9921f, 0.24705f, 0.57254f);
-                                break;
-                            }
+                            switch (m->id) {    // scatterRay wgsl:174-202
+                            case 0u: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
+                            case 1u: work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
+                            case 2u: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
+                            case 3u: work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
+                            default: work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
                             }
                             ro = hp;
                             rd = ndir;
@@ -580,6 +654,206 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_kernel(RenderArgs A)
     }
 }
 
+// shading routines ("ops") a path can wait for: the five scatter routines of scatterRay
+// (wgsl:174-314) and OP_GEN = finish the path (add throughput x sky) + start the next work item
+constexpr uint32_t OP_LAMBERTIAN = 0, OP_METAL = 1, OP_DIELECTRIC = 2, OP_CHECKER = 3, OP_MISSING = 4, OP_GEN = 5,
+                   OP_NONE = 6, kNumOps = 6;
+
+// ------------------------------------------------------------------------------------------
+// render_pt_pool — wave-private path pool: every wave-instruction runs ONE shading routine
+// ------------------------------------------------------------------------------------------
+//
+// The strip kernel loses half its lanes to divergence: a wave's 64 samples start on the same
+// pixel (same material) but scatter to different materials or leave the scene, and the per-lane
+// material switch runs every routine present.  Here a wave instead keeps SLOTS paths in LDS:
+//   q0 = {ro.xyz, t}  q1 = {rd.xyz, best}  q2 = {thr.xyz, rng}   (48 B, ds_*_b128)
+//   flags = pixel | bounce << 8 | has_miss << 16
+// and every slot id sits in exactly one of six ring queues — the routine ("op") its path waits
+// for.  Each step the wave pops up to 64 ids from its FULLEST queue, gathers those paths, runs
+// that one routine for all lanes, then the common tail (bounce limit, nearest hit,
+// classification) and pushes each id to the queue of its next op.  A wave owns its pool outright:
+// a strip of kStripPixels pixels = strip_pixels x spp work items (item = sample * strip_pixels +
+// pixel), their 64-bit accumulators, the item counter and all queue heads/tails in SGPRs.
+// Nothing is shared between waves after the scene has been staged: no barrier, no inter-wave
+// atomic.  (A block-level pool with barriers was measured 20 % slower)
+template <uint32_t SLOTS>
+struct WavePoolLayout {
+    static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
+    static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
+    static constexpr uint32_t kOffFlags = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32
+    static constexpr uint32_t kOffRing  = kOffFlags + SLOTS * 4;              // [kNumOps][SLOTS] u8 (ring capacity = SLOTS)
+    static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * SLOTS + 15) / 16) * 16;
+};
+
+template <uint32_t THREADS, uint32_t SLOTS, bool COUNT, bool HOSEK>
+__global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
+{
+    using Lay = WavePoolLayout<SLOTS>;
+    static_assert(SLOTS >= 64 && SLOTS <= 256 && (SLOTS & (SLOTS - 1)) == 0, "slot ids are 8 bit, ring capacity = SLOTS");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SceneLds S = stage_scene<true>(A, smem, HOSEK);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t scene_bytes = (uint32_t)scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK);
+    unsigned char* pool = smem + scene_bytes + wave * Lay::kBytes;
+    uint4* const L_state = reinterpret_cast<uint4*>(pool + Lay::kOffState);
+    unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
+    uint32_t* const L_flags = reinterpret_cast<uint32_t*>(pool + Lay::kOffFlags);
+    unsigned char* const L_ring = pool + Lay::kOffRing;
+
+    const uint32_t npix = A.out_rows * A.width;
+    const CamRegs C = load_camera(S, A);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    Work<COUNT> work;
+    work.clear();
+
+    for (;;) {
+        const uint32_t strip = next_unit(A, lane);
+        if (strip >= A.n_units) break;
+        const uint32_t base_pix = strip * kStripPixels;
+        const uint32_t strip_pixels = (npix - base_pix < kStripPixels) ? (npix - base_pix) : kStripPixels;
+        const uint32_t total_items = strip_pixels * A.spp;
+        // scalar (per-strip) pixel addressing: one division here instead of two per work item
+        const uint32_t base_ci = base_pix / A.width;
+        const uint32_t base_x = base_pix - base_ci * A.width;
+        const bool wide = A.width >= kStripPixels;            // a strip then spans at most two rows
+        const uint32_t row0 = abs_row(A, base_ci);
+        const uint32_t row1 = (base_ci + 1 < A.out_rows) ? abs_row(A, base_ci + 1) : row0;
+
+        // all slots start in the OP_GEN queue
+        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * SLOTS + s] = (unsigned char)s; L_flags[s] = 0u; }
+        if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
+        uint32_t head[kNumOps], tail[kNumOps];             // wave-uniform (SGPRs)
+#pragma unroll
+        for (uint32_t k = 0; k < kNumOps; ++k) { head[k] = 0; tail[k] = (k == OP_GEN) ? SLOTS : 0u; }
+        uint32_t next_item = 0;
+
+        for (;;) {
+            // ---- pick the fullest queue ----
+            uint32_t my_k = OP_NONE, my_n = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kNumOps; ++k) {
+                const uint32_t c = tail[k] - head[k];
+                if (c > my_n) { my_n = c; my_k = k; }
+            }
+            if (my_n == 0) break;                          // every queue empty: strip finished
+            my_n = (my_n > 64u) ? 64u : my_n;
+            uint32_t my_begin = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kNumOps; ++k) {
+                if (my_k == k) { my_begin = head[k]; head[k] += my_n; }
+            }
+
+            // ---- pop + gather ----
+            const bool has = lane < my_n;
+            const uint32_t slot = has ? (uint32_t)L_ring[my_k * SLOTS + ((my_begin + lane) & (SLOTS - 1u))] : 0u;
+            const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
+            const uint32_t fl = L_flags[slot];
+            f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));
+            const float t_hit = from_bits(q0.w);
+            f3 rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
+            const int best = has ? (int)q1.w : 0;
+            f3 thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
+            Rng rng;
+            rng.state = q2.w;
+            uint32_t pix = fl & 0xffu;
+            uint32_t bounce = (fl >> 8) & 0xffu;
+            bool alive = has;
+            if constexpr (COUNT) { if (lane == 0) work.add(kCntWaveIters); }
+
+            if (my_k == OP_GEN) {
+                // finish the previous path of this slot ...
+                if (has && ((fl >> 16) & 1u)) {
+                    work.add(kCntSky);
+                    const f3 c = sky_color<HOSEK>(S, rd);
+                    atomicAdd(&L_acc[pix * 3 + 0], (unsigned long long)to_fixed(thr.x * c.x));
+                    atomicAdd(&L_acc[pix * 3 + 1], (unsigned long long)to_fixed(thr.y * c.y));
+                    atomicAdd(&L_acc[pix * 3 + 2], (unsigned long long)to_fixed(thr.z * c.z));
+                }
+                // ... and start the next work item in it
+                const uint32_t item = next_item + lane;
+                next_item += my_n;
+                alive = has && item < total_items;
+                uint32_t sample;
+                if (strip_pixels == kStripPixels) { sample = item / kStripPixels; pix = item % kStripPixels; }   // shifts
+                else { sample = item / strip_pixels; pix = item - sample * strip_pixels; }
+                // pixel -> (x, y): the strip starts at (base_x, row0) and may wrap into following rows
+                uint32_t x = base_x + pix, y = row0;
+                if (wide) { if (x >= A.width) { x -= A.width; y = row1; } }
+                else { const uint32_t pi = base_pix + pix; const uint32_t ci = pi / A.width; x = pi - ci * A.width; y = abs_row(A, ci); }
+                generate_primary(A, C, x, y, A.sample_begin + sample, rng, ro, rd);
+                thr = mk(1, 1, 1);
+                bounce = 0;
+            } else {
+                // sphereIntersection wgsl:431-440, then ONE scatter routine for the whole wave
+                const PreparedSphere sp = S.spheres[best];
+                const f3 hp = fma3(t_hit, rd, ro);
+                const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
+                const PreparedMaterial* m = &S.pmats[has ? sp.material_idx : 0u];
+                f3 ndir = rd, att = mk(1, 1, 1);
+                if (has) {
+                    switch (my_k) {                        // wave-uniform
+                    case OP_LAMBERTIAN: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
+                    case OP_METAL:      work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
+                    case OP_DIELECTRIC: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
+                    case OP_CHECKER:    work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
+                    default:            work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
+                    }
+                }
+                ro = hp;
+                rd = ndir;
+                thr = thr * att;
+                bounce += 1;
+            }
+
+            // common tail: bounce limit (wgsl:130), nearest hit, classification
+            uint32_t new_op = OP_NONE;
+            uint32_t miss = 0;
+            const bool trace = alive && bounce < A.num_bounces;
+            if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
+            float closest;
+            const int nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
+            if (alive) {
+                new_op = OP_GEN;                           // path ended (bounce limit: contributes nothing)
+                if (trace) {
+                    if (nb >= 0) {
+                        work.add(kCntHits);
+                        const uint32_t id = S.pmats[S.spheres[nb].material_idx].id;
+                        new_op = (id < 4u) ? ((id == 0u) ? OP_LAMBERTIAN : (id == 1u) ? OP_METAL : (id == 2u) ? OP_DIELECTRIC : OP_CHECKER)
+                                           : OP_MISSING;
+                    } else {
+                        miss = 1;                          // left the scene: OP_GEN adds throughput x sky
+                    }
+                }
+            }
+            if (has) {
+                L_state[slot * 3 + 0] = make_uint4(bits(ro.x), bits(ro.y), bits(ro.z), bits(closest));
+                L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), (uint32_t)nb);
+                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), rng.state);
+                L_flags[slot] = pix | (bounce << 8) | (miss << 16);
+            }
+            // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
+#pragma unroll
+            for (uint32_t k = 0; k < kNumOps; ++k) {
+                const unsigned long long mk_ = __ballot(new_op == k);
+                if (new_op == k) L_ring[k * SLOTS + ((tail[k] + (uint32_t)__popcll(mk_ & lt_mask)) & (SLOTS - 1u))] = (unsigned char)slot;
+                tail[k] += (uint32_t)__popcll(mk_);
+            }
+        }
+
+        // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
+        if (lane < strip_pixels) {
+            const uint32_t rgba = pack_rgba(resolve_channel(L_acc[lane * 3 + 0], A.spp, A.flags),
+                                            resolve_channel(L_acc[lane * 3 + 1], A.spp, A.flags),
+                                            resolve_channel(L_acc[lane * 3 + 2], A.spp, A.flags));
+            A.out[base_pix + lane] = rgba;
+        }
+        work.flush(A.counters, lane);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // de-interleave: root side of the multi-GPU gather (tile-interleaved parts -> band image)
 // ------------------------------------------------------------------------------------------
@@ -602,30 +876,76 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(DeinterleaveArgs D)
 // launchers
 // ------------------------------------------------------------------------------------------
 
-size_t scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool hosek)
+size_t scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek)
 {
-    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) + (size_t)n_mats * sizeof(MirtMaterial) +
-           (hosek ? sizeof(MirtSkyState) : 0);
+    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) +
+           (size_t)n_mats * (pt ? sizeof(PreparedMaterial) : sizeof(MirtMaterial)) + (hosek ? sizeof(MirtSkyState) : 0);
+}
+
+
+template <typename K>
+static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a, hipStream_t stream)
+{
+    if (a.lds_bytes > 48u * 1024u) {        // more than the default dynamic-LDS window: ask for it
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(render_parity_kernel, dim3(grid_blocks), dim3(kBlockThreads), a.lds_bytes, stream, a);
-    return hipGetLastError();
+    return launch_with_lds(render_parity_kernel, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
-hipError_t launch_pt(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const dim3 g(grid_blocks), b(kBlockThreads);
-    if (count) {
-        if (hosek) hipLaunchKernelGGL((render_pt_kernel<true, true>), g, b, a.lds_bytes, stream, a);
-        else       hipLaunchKernelGGL((render_pt_kernel<true, false>), g, b, a.lds_bytes, stream, a);
-    } else {
-        if (hosek) hipLaunchKernelGGL((render_pt_kernel<false, true>), g, b, a.lds_bytes, stream, a);
-        else       hipLaunchKernelGGL((render_pt_kernel<false, false>), g, b, a.lds_bytes, stream, a);
+    if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_strip_kernel<true, false>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_strip_kernel<false, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_strip_kernel<false, false>, g, b, a, stream);
+}
+
+template <uint32_t T, uint32_t SL>
+static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(T);
+    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, true, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_kernel<T, SL, true, false>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, false, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<T, SL, false, false>, g, b, a, stream);
+}
+
+// pool geometries {threads per block, slots per wave}; [0] is the default.  128 slots x 52 B keeps a
+// wave's pool under 8 KB, so that 20 waves (the VGPR limit) still fit a CU's 160 KB of LDS;
+// measured on config 3: 256 slots -> 8 waves/CU, 1.7x slower; 64 slots -> 68 % lane use, 1.4x slower.
+static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 128, 128, 0 }, { 512, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
+
+uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
+
+PoolConfig pool_config(uint32_t i)
+{
+    PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
+    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
+                                                                                                : WavePoolLayout<256>::kBytes;
+    c.lds_bytes = per_wave * (c.threads / 64);
+    return c;
+}
+
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream)
+{
+    const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
+    switch (cfg) {
+    case 1:  return launch_pool_cfg<128, 128>(a, grid_blocks, count, hosek, stream);
+    case 2:  return launch_pool_cfg<512, 128>(a, grid_blocks, count, hosek, stream);
+    case 3:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
+    case 4:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
+    default: return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream)
