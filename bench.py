@@ -65,7 +65,7 @@ def profiled_traffic(kernel: str):
             d = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if kernel.startswith(d.get("kernel", "\0")) and "hbm_bytes_per_launch" in d.get("derived", {}):
+        if d.get("kernel_id") == kernel and "hbm_bytes_per_launch" in d.get("derived", {}):
             best = (d["derived"]["hbm_bytes_per_launch"], f.name)
     return best
 
@@ -87,13 +87,14 @@ def cpu_baseline(m, sd, target_seconds: float = 15.0) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    p = m.make_params(WIDTH, HEIGHT, 1, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
-    ob.render(sd, p, n_threads=cores)
-    probe_s = ob.stats()["kernel_ms"] / 1e3
-    spp = int(max(1, min(SPP, round(target_seconds / max(probe_s, 1e-3)))))
-    p = m.make_params(WIDTH, HEIGHT, spp, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
-    ob.render(sd, p, n_threads=cores)
-    secs = ob.stats()["kernel_ms"] / 1e3
+    spp, secs = 4, 0.0
+    for _ in range(4):                                   # grow the sample until it is worth ~target_seconds of CPU work
+        p = m.make_params(WIDTH, HEIGHT, spp, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
+        ob.render(sd, p, n_threads=cores)
+        secs = ob.stats()["kernel_ms"] / 1e3
+        if secs >= 0.6 * target_seconds or spp >= SPP:
+            break
+        spp = int(max(spp + 1, min(SPP, round(spp * target_seconds / max(secs, 1e-3)))))
     return {"value": round(WIDTH * HEIGHT * spp / secs / 1e6, 3), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
             "sample": f"same scene and frame ({WIDTH}x{HEIGHT}, {BOUNCES} bounces) at {spp} spp instead of {SPP} "
@@ -179,7 +180,10 @@ def main() -> int:
         total_samples = WIDTH * HEIGHT * SPP
         value = total_samples * args.steps / elapsed / 1e6
         flops = algorithmic_flops(work)
-        traffic = profiled_traffic("render_pt_kernel<false") if world == 1 else None
+        kernel_name = "render_pt_pool_kernel<256,128,false,false>"     # default schedule for spp >= 48 (mirt_api.hip)
+        if base.flags & m.MIRT_FLAG_KERNEL_STRIP:
+            kernel_name = "render_pt_strip_kernel<false,false>"
+        traffic = profiled_traffic(kernel_name) if world == 1 else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
         out_bytes = frame.rows * WIDTH * 4
         in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96
@@ -210,7 +214,7 @@ def main() -> int:
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 4),
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
-                "kernel": "render_pt_kernel<false,false>",
+                "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 3),

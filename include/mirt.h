@@ -262,6 +262,25 @@ int mirt_ctx_synchronize(MirtContext* ctx);
 /* Stats of the last completed render call (synchronises the context first). */
 int mirt_ctx_get_stats(MirtContext* ctx, MirtStats* out);
 
+/* ---- progressive accumulation: what `RenderProgress::next_frame` (mod.rs:615-679) and the f32
+ * image buffer of fsMain (wgsl:61-80) do across frames.  The context owns one accumulation buffer of
+ * EXACT 64-bit fixed-point sums (3 per pixel, 2^-20 units), so frames add up bit-identically to
+ * a single launch with the total sample count.  Path-traced mode only. ---- */
+
+/* (Re)size the buffer for the rows `params` selects and clear it (`clear_accumulated_samples`). */
+int mirt_ctx_accum_reset(MirtContext* ctx, const MirtParams* params);
+/* Render params->spp further samples of every pixel (samples accumulated so far .. +spp of the RNG
+ * stream; params->sample_begin is ignored) and add them to the buffer.  Asynchronous on `hip_stream`
+ * (NULL = the context's stream). */
+int mirt_ctx_accum_add(MirtContext* ctx, const MirtParams* params, void* hip_stream);
+/* Samples per pixel accumulated since the last reset (`accumulated_samples_per_pixel`). */
+uint32_t mirt_ctx_accum_samples(const MirtContext* ctx);
+/* Resolve the buffer (mean over the accumulated samples, tone curves per params->flags) into
+ * host memory, RGBA8; blocking. */
+int mirt_ctx_accum_resolve(MirtContext* ctx, const MirtParams* params, uint8_t* out_rgba8, size_t out_len);
+/* Copy the raw sums to the host: pixels x 3 uint64 (the fp32-intermediate view used by tests). */
+int mirt_ctx_accum_read(MirtContext* ctx, uint64_t* out_sums, size_t out_len_u64);
+
 /* One-shot convenience: create context on `device`, set scene, render to host, destroy.
  * Signature a Rust `set_data` binds when it does not keep a context. */
 int mirt_render(const MirtScene* scene, const MirtParams* params, int device,

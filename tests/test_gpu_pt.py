@@ -228,3 +228,41 @@ def test_full_size_pt_properties(gpu_ctx, oracle):
         img = gpu_ctx.render(m.multi_gpu.part_params(plain, r, 8, 4))
         parts[r, :img.shape[0]] = img
     assert_images_equal(m.multi_gpu.assemble_host(parts, plain, 8, 4), full, "8-way tiles 1080p")
+
+
+@pytest.mark.parametrize("kernel", [m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
+def test_progressive_accumulation_is_exact(gpu_ctx, oracle, kernel):
+    """mirt_ctx_accum_*: frames of 10 + 14 + 40 samples add up, bit for bit, to the oracle's exact
+    fixed-point sums for 64 samples (the fp32-intermediate check of the parity claim: every sample's
+    radiance, quantised to 2^-20, must be identical), and resolve to the one-shot image."""
+    w, h = 96, 54
+    sd = scene_data("main_rs_scene", w, h)
+    gpu_ctx.set_scene(sd)
+    mk = lambda spp: m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=kernel)   # noqa: E731
+    gpu_ctx.accum_reset(mk(10))
+    for spp in (10, 14, 40):
+        gpu_ctx.accum_add(mk(spp))
+    assert gpu_ctx.accum_samples() == 64
+    want_sums = oracle.render_pt_sums(sd, m.make_params(w, h, 64, mode=m.MIRT_MODE_PT, num_bounces=8))
+    assert np.array_equal(gpu_ctx.accum_read(mk(10)), want_sums)
+    assert_images_equal(gpu_ctx.accum_resolve(mk(10)), oracle.render(sd, m.make_params(w, h, 64, mode=m.MIRT_MODE_PT)), "resolve")
+    assert_images_equal(gpu_ctx.accum_resolve(mk(10)), gpu_ctx.render(mk(64)), "one-shot")
+    # reset really clears
+    gpu_ctx.accum_reset(mk(10))
+    assert gpu_ctx.accum_samples() == 0 and not gpu_ctx.accum_read(mk(10)).any()
+
+
+def test_raytracer_render_frame_progression(oracle):
+    """The reference's progressive loop (mod.rs:626-670): N spp per frame until max, then frames stop adding."""
+    scene, cam = m.scenes.three_spheres()
+    rp = m.RenderParams(camera=cam, viewport_size=(64, 40), sampling=m.SamplingParams(12, 4, 8))
+    rt = m.Raytracer(scene, rp)
+    sd = rt.scene_data()
+    for k in (4, 8, 12, 12, 12):
+        img = rt.render_frame()
+        assert_images_equal(img, oracle.render(sd, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8)), f"after {k} spp")
+    assert rt.progress() == 1.0
+    rt.set_render_params(rp)               # any parameter change resets the accumulation (mod.rs:385)
+    assert rt.progress() == 0.0
+    assert_images_equal(rt.render_frame(), oracle.render(sd, m.make_params(64, 40, 4, mode=m.MIRT_MODE_PT, num_bounces=8)), "after reset")
+    rt.close()

@@ -24,7 +24,8 @@ N_CU, SIMD_PER_CU = 256, 4
 
 def main() -> int:
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    needle = sys.argv[2] if len(sys.argv) > 2 else "render_pt_kernel<false"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "render_pt_pool_kernel<256u, 128u, false, false>"
+    kernel_id = sys.argv[3] if len(sys.argv) > 3 else "render_pt_pool_kernel<256,128,false,false>"
     src = ROOT / "gpurun_out" / f"prof_{tag}"
     dst = ROOT / "profiles"
     dst.mkdir(exist_ok=True)
@@ -75,7 +76,7 @@ def main() -> int:
         d["hbm_gbs"] = d["hbm_bytes_per_launch"] / secs / 1e9
     if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
         d["l2_hit_rate_pct"] = 100.0 * avg["TCC_HIT_sum"] / max(1.0, avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
-    out = {"tag": tag, "kernel": needle, "kernel_avg_ms_trace_pass": kernel_ns / 1e6, "calls_in_trace": calls,
+    out = {"tag": tag, "kernel": needle, "kernel_id": kernel_id, "kernel_avg_ms_trace_pass": kernel_ns / 1e6, "calls_in_trace": calls,
            "dispatch": meta, "counters_per_launch_avg": avg, "derived": d,
            "notes": ["each --pmc group was collected in its own run (tools/profile_bench.sh)",
                      "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of coalesced reads); WRITE_SIZE taken as is",

@@ -111,6 +111,26 @@ class Context:
                                                  C.c_void_p(d_out), out_nbytes,
                                                  C.c_void_p(stream) if stream else None))
 
+    # ---- progressive accumulation (RenderProgress::next_frame + the shader's image buffer) ----
+    def accum_reset(self, params: _abi.MirtParams) -> None:
+        check(lib().mirt_ctx_accum_reset(self._h, C.byref(params)))
+
+    def accum_add(self, params: _abi.MirtParams, stream: int = 0) -> None:
+        check(lib().mirt_ctx_accum_add(self._h, C.byref(params), C.c_void_p(stream) if stream else None))
+
+    def accum_samples(self) -> int:
+        return int(lib().mirt_ctx_accum_samples(self._h))
+
+    def accum_resolve(self, params: _abi.MirtParams) -> np.ndarray:
+        out = np.empty((params_out_rows(params), params.width, 4), dtype=np.uint8)
+        check(lib().mirt_ctx_accum_resolve(self._h, C.byref(params), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def accum_read(self, params: _abi.MirtParams) -> np.ndarray:
+        out = np.empty((params_out_rows(params), params.width, 3), dtype=np.uint64)
+        check(lib().mirt_ctx_accum_read(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
     def synchronize(self) -> None:
         check(lib().mirt_ctx_synchronize(self._h))
 

@@ -123,6 +123,7 @@ struct MirtContext {
     uint32_t n_spheres = 0, n_mats = 0;
     uint64_t n_texels = 0;
     bool     have_sky = false;
+    uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
     bool     mats_ok_for_pt = false;      // validation results cached at set_scene
     int      pt_scene_status = MIRT_OK;
     int      parity_scene_status = MIRT_OK;
@@ -140,6 +141,11 @@ struct MirtContext {
     uint32_t*           d_work_counter = nullptr;
     uint32_t*           d_out = nullptr;     // scratch framebuffer for host-output renders
     size_t              cap_out = 0;
+    unsigned long long* d_accum = nullptr;   // progressive accumulation: [pixels][3] exact sums
+    size_t              cap_accum = 0;
+    uint64_t            accum_pixels = 0;
+    uint32_t            accum_samples = 0;
+    uint32_t            accum_width = 0, accum_rows = 0;
 
     MirtStats stats{};
     bool      stats_counted = false;
@@ -300,7 +306,7 @@ void mirt_ctx_destroy(MirtContext* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_texels);
-    (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out);
+    (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -326,6 +332,14 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         const MirtMaterial& m = s->materials[i];
         if ((m.id == 0 || m.id == 1 || m.id == 3) && !desc_ok(m.desc1, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
         if (m.id == 3 && !desc_ok(m.desc2, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
+    }
+    {   // how many different scatter routines can a path meet?  (decides the path-traced schedule)
+        uint32_t seen = 0;
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            const uint32_t mi = s->spheres[i].material_idx;
+            if (mi < s->n_materials) { const uint32_t id = s->materials[mi].id; seen |= 1u << (id < 4u ? id : 4u); }
+        }
+        c->n_shading_routines = (uint32_t)__builtin_popcount(seen);
     }
     c->parity_scene_status = MIRT_OK;
     if (s->n_spheres > 0) {   // layer.rs:345-349 reads material_data[2] on every primary hit
@@ -435,7 +449,8 @@ static int fold_events(MirtContext* c)
     return MIRT_OK;
 }
 
-static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream)
+static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream,
+                         unsigned long long* d_accum = nullptr)
 {
     if (c->ev_used == c->ev_begin.size()) {      // pool exhausted: fold (one sync per 64 launches)
         const int rc = fold_events(c);
@@ -451,20 +466,26 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const size_t scene_lds = mirt::scene_lds_bytes(c->n_spheres, c->n_mats, pt, hosek);
     // kernel choice (path-traced mode): the pooled kernel needs enough samples per tile to keep
     // its path pool full, 8-bit bounce counters and room for the pool beside the scene in LDS
-    bool pool = pt && p->spp >= mirt::kPoolMinSpp;
-    if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
-    if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
     uint32_t pool_cfg = mirt::kDefaultPoolConfig;
     if (const char* e = std::getenv("MIRT_POOL_CONFIG")) {          // tuning knob: geometry of the path pool
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) pool_cfg = (uint32_t)v;
     }
     const mirt::PoolConfig pc = mirt::pool_config(pool_cfg);
+    // Default schedule: the pooled kernel pays off when paths diverge over >= 2 scatter routines,
+    // a strip holds enough samples to keep the pool full, and the pools still leave >= 16 waves
+    // per CU resident beside the scene tables (measured: 1 sphere 0.9x, 3 spheres 1.4x, 5 spheres
+    // 1.5x, 484 spheres 0.75x of the strip kernel).
+    const size_t lds_pool_block = scene_lds + pc.lds_bytes;
+    const uint32_t pool_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_block ? lds_pool_block : 1)) * (pc.threads / 64u);
+    bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_waves_per_cu >= 16;
+    if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
+    if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
     if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block) pool = false;
 
     mirt::RenderArgs a{};
     a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
-    a.out = d_out; a.counters = c->d_counters; a.work_counter = c->d_work_counter;
+    a.out = d_out; a.counters = c->d_counters; a.work_counter = c->d_work_counter; a.accum = d_accum;
     a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
     a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
@@ -477,7 +498,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     uint32_t blocks;
     if (pool) {
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
-        const uint32_t by_waves = 20u / (pc.threads / 64u);   // ~95 VGPRs -> 5 waves per SIMD = 20 per CU
+        const uint32_t by_waves = 24u / (pc.threads / 64u);   // upper bound; the hardware admits what VGPRs/LDS allow
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu == 0u) per_cu = 1u;
         blocks = (uint32_t)c->cu_count * per_cu;
@@ -568,6 +589,66 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats_counted = false;
     }
     *out = c->stats;
+    return MIRT_OK;
+}
+
+int mirt_ctx_accum_reset(MirtContext* c, const MirtParams* p)
+{
+    int rc = check_params(c, p);
+    if (rc != MIRT_OK) return rc;
+    if (p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "progressive accumulation exists in path-traced mode only");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t npix = (uint64_t)out_rows(p) * p->width;
+    if ((rc = ensure_capacity(&c->d_accum, &c->cap_accum, (size_t)npix * 3)) != MIRT_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_accum, 0, (size_t)npix * 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->accum_pixels = npix;
+    c->accum_samples = 0;
+    c->accum_width = p->width;
+    c->accum_rows = out_rows(p);
+    return MIRT_OK;
+}
+
+int mirt_ctx_accum_add(MirtContext* c, const MirtParams* p, void* hip_stream)
+{
+    int rc = check_params(c, p);
+    if (rc != MIRT_OK) return rc;
+    if (p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "progressive accumulation exists in path-traced mode only");
+    if (!c->d_accum || c->accum_width != p->width || c->accum_rows != out_rows(p))
+        return fail(MIRT_ERR_OUT_BUFFER, "accumulation buffer does not match these params: call mirt_ctx_accum_reset first");
+    HIP_TRY(hipSetDevice(c->device));
+    MirtParams q = *p;
+    q.sample_begin = c->accum_samples;                  // continue the RNG stream where the last frame stopped
+    rc = launch_render(c, &q, nullptr, hip_stream ? (hipStream_t)hip_stream : c->stream, c->d_accum);
+    if (rc == MIRT_OK) c->accum_samples += p->spp;
+    return rc;
+}
+
+uint32_t mirt_ctx_accum_samples(const MirtContext* c) { return c ? c->accum_samples : 0u; }
+
+int mirt_ctx_accum_resolve(MirtContext* c, const MirtParams* p, uint8_t* out, size_t out_len)
+{
+    if (!c || !p || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/params/out is null");
+    if (!c->d_accum || c->accum_samples == 0) return fail(MIRT_ERR_NO_SCENE, "nothing accumulated yet");
+    if (out_len < c->accum_pixels * 4) return fail(MIRT_ERR_OUT_BUFFER, "output buffer holds %zu bytes, %llu needed", out_len,
+                                                    (unsigned long long)c->accum_pixels * 4);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_capacity(&c->d_out, &c->cap_out, (size_t)c->accum_pixels)) != MIRT_OK) return rc;
+    HIP_TRY(mirt::launch_resolve(c->d_accum, c->d_out, c->accum_pixels, c->accum_samples, p->flags, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)c->accum_pixels * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_ctx_accum_read(MirtContext* c, uint64_t* out_sums, size_t out_len_u64)
+{
+    if (!c || !out_sums) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
+    if (!c->d_accum) return fail(MIRT_ERR_NO_SCENE, "nothing accumulated yet");
+    if (out_len_u64 < c->accum_pixels * 3) return fail(MIRT_ERR_OUT_BUFFER, "output buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_sums, c->d_accum, (size_t)c->accum_pixels * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MIRT_OK;
 }
 

@@ -118,25 +118,28 @@ MIRT_DEV float atan2_(float y, float x)
     const bool xbig = ax > ay;
     const float mx = xbig ? ax : ay;
     const float mn = xbig ? ay : ax;
-    if (!(mx > 0.0f)) return 0.0f;
-    const float a = mn / mx;
+    const float a = mn / mx;                               // 0/0 -> NaN, discarded by the last select
     const float z = a * a;
     float r = fma_(a * z, horner(kAtan, z), a);
     r = (ay > ax) ? (kFracPi2 - r) : r;
     r = (x < 0.0f) ? (kPi - r) : r;
-    return (y < 0.0f) ? -r : r;
+    r = (y < 0.0f) ? -r : r;
+    return (mx > 0.0f) ? r : 0.0f;                         // branch-free: selects only
 }
 
 // log2 of a finite positive float.
 MIRT_DEV float log2_(float x)
 {
     constexpr float kLog2[10] = { 0x1.7154760000000p+0f, -0x1.7154700000000p-1f, 0x1.ec70aa0000000p-2f, -0x1.715a700000000p-2f, 0x1.277a520000000p-2f, -0x1.eab7aa0000000p-3f, 0x1.a38c680000000p-3f, -0x1.87f6a20000000p-3f, 0x1.7a63a00000000p-3f, -0x1.b84fb60000000p-4f };
-    uint32_t u = bits(x);
-    int eadj = 0;
-    if (u < 0x00800000u) { x = x * 16777216.0f; u = bits(x); eadj = -24; }
-    int e = (int)(u >> 23) - 127;
-    uint32_t m = (u & 0x007fffffu) | 0x3f800000u;
-    if (m >= 0x3fb504f3u) { m -= 0x00800000u; e += 1; }
+    const uint32_t u0 = bits(x);
+    const bool sub = u0 < 0x00800000u;                     // subnormal: scale by 2^24 first (select, no branch)
+    const uint32_t u = sub ? bits(x * 16777216.0f) : u0;
+    const int eadj = sub ? -24 : 0;
+    const int e0 = (int)(u >> 23) - 127;
+    const uint32_t m0 = (u & 0x007fffffu) | 0x3f800000u;
+    const bool big = m0 >= 0x3fb504f3u;                    // m >= sqrt(2): halve
+    const uint32_t m = big ? (m0 - 0x00800000u) : m0;
+    const int e = big ? (e0 + 1) : e0;
     const float f = from_bits(m) - 1.0f;
     return fma_(f, horner(kLog2, f), (float)(e + eadj));
 }
@@ -146,19 +149,25 @@ MIRT_DEV float exp2_(float y)
 {
     constexpr float kExp2[7] = { 0x1.62e4300000000p-1f, 0x1.ebfbe00000000p-3f, 0x1.c6b08e0000000p-5f, 0x1.3b2a1c0000000p-7f, 0x1.5d879e0000000p-10f, 0x1.4440000000000p-13f, 0x1.00a5800000000p-16f };
     constexpr float kMagic = 12582912.0f;
-    if (!(y < 128.0f)) return __builtin_inff();
-    if (!(y >= -126.0f)) return 0.0f;
-    const float nf = (y + kMagic) - kMagic;
-    const float f = y - nf;
+    const bool hi = !(y < 128.0f);                          // -> +inf
+    const bool lo = !(y >= -126.0f);                        // -> 0 (also NaN)
+    const float yc = (hi || lo) ? 0.0f : y;                 // keep the main path in range; selects, no branches
+    const float nf = (yc + kMagic) - kMagic;
+    const float f = yc - nf;
     const int n = (int)nf;
     const float p = fma_(f, horner(kExp2, f), 1.0f);
     const int n1 = n >> 1, n2 = n - n1;
     const float s1 = from_bits((uint32_t)(n1 + 127) << 23);
     const float s2 = from_bits((uint32_t)(n2 + 127) << 23);
-    return (p * s1) * s2;
+    const float r = (p * s1) * s2;
+    return hi ? __builtin_inff() : (lo ? 0.0f : r);
 }
 
-MIRT_DEV float pow_pos(float x, float y) { return (x > 0.0f) ? exp2_(y * log2_(x)) : 0.0f; }
+MIRT_DEV float pow_pos(float x, float y)
+{
+    const float r = exp2_(y * log2_((x > 0.0f) ? x : 1.0f));      // evaluated for every lane, selected below
+    return (x > 0.0f) ? r : 0.0f;
+}
 MIRT_DEV float exp_(float x) { return exp2_(x * 1.44269504f); }
 
 // ---- 3-vectors ----

@@ -62,6 +62,7 @@ struct RenderArgs {
     uint32_t*               out;           // compact RGBA8, one u32 per pixel
     unsigned long long*     counters;      // [kNumCounters], COUNT builds only
     uint32_t*               work_counter;  // dynamic work dispenser, zeroed before every launch
+    unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;
     uint32_t n_spheres, n_mats;
     uint32_t width, height, spp, num_bounces, flags, seed_mix, sample_begin;
@@ -85,6 +86,8 @@ struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream);
+hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
+                          uint32_t flags, hipStream_t stream);
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream);
 size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek);
 

@@ -93,9 +93,9 @@ MIRT_DEV uint32_t next_unit(const RenderArgs& A, uint32_t lane)
 
 MIRT_DEV uint32_t sat_u32(float f)   // Rust `as u32` / WGSL u32(): truncate, saturate, NaN -> 0
 {
-    if (!(f > 0.0f)) return 0u;
-    if (f >= 4294967296.0f) return 0xffffffffu;
-    return (uint32_t)f;
+    const float c = (f > 0.0f) ? f : 0.0f;                  // NaN and negatives -> 0
+    const uint32_t v = (uint32_t)((c >= 4294967296.0f) ? 0.0f : c);
+    return (c >= 4294967296.0f) ? 0xffffffffu : v;
 }
 
 MIRT_DEV uint32_t sat_u8(float f)    // Rust `as u8` (math.rs:15-17)
@@ -363,17 +363,17 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
         const float b = dot(oc, rd);
         const float cq = dot(oc, oc) - s4.w;
         const float disc = fma_(b, b, -(a * cq));
-        if (alive && disc > 0.0f) {
+        if (alive && disc > 0.0f) {                              // skipped when no lane of the wave can hit
             const float sq = sqrt_(disc);
-            float t = (-b - sq) * inv_a;
-            bool ok = (t < closest) && (t > kMinT);
-            work.add(kCntRoots);
-            if (!ok) {
-                t = (-b + sq) * inv_a;
-                ok = (t < closest) && (t > kMinT);
-                work.add(kCntRoots);
-            }
-            if (ok) { closest = t; best = (int)i; }
+            const float t0 = (-b - sq) * inv_a;
+            const float t1 = (-b + sq) * inv_a;
+            const bool ok0 = (t0 < closest) && (t0 > kMinT);    // first root, else second (wgsl:415-425), branch-free
+            const bool ok1 = (t1 < closest) && (t1 > kMinT);
+            work.add(kCntRoots, ok0 ? 1u : 2u);
+            const float t = ok0 ? t0 : t1;
+            const bool ok = ok0 || ok1;
+            closest = ok ? t : closest;
+            best = ok ? (int)i : best;
         }
     }
     closest_out = closest;
@@ -532,8 +532,8 @@ MIRT_DEV f3 sky_color(const SceneLds& S, f3 d)
 
 MIRT_DEV uint32_t to_fixed(float c)          // 2^-20 units, clamped to [0, 4096)
 {
-    if (!(c > 0.0f)) return 0u;
-    float s = c * 1048576.0f;
+    const float p = (c > 0.0f) ? c : 0.0f;                  // NaN and negatives -> 0 (select, no branch)
+    float s = p * 1048576.0f;
     s = (s >= 4294967040.0f) ? 4294967040.0f : s;
     return (uint32_t)s;
 }
@@ -645,11 +645,15 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
             acc_r = wave_sum_u64(acc_r);
             acc_g = wave_sum_u64(acc_g);
             acc_b = wave_sum_u64(acc_b);
-            const uint32_t rgba = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
-                                            resolve_channel(acc_b, A.spp, A.flags));
-            if (lane == p) my_px = rgba;
+            if (A.accum) {                       // progressive mode: add the exact sums, resolve later
+                if (lane == 0) { A.accum[3ull * pi + 0] += acc_r; A.accum[3ull * pi + 1] += acc_g; A.accum[3ull * pi + 2] += acc_b; }
+            } else {
+                const uint32_t rgba = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
+                                                resolve_channel(acc_b, A.spp, A.flags));
+                if (lane == p) my_px = rgba;
+            }
         }
-        if (lane < kStripPixels && base + lane < npix) A.out[base + lane] = my_px;
+        if (!A.accum && lane < kStripPixels && base + lane < npix) A.out[base + lane] = my_px;
         work.flush(A.counters, lane);
     }
 }
@@ -676,20 +680,24 @@ constexpr uint32_t OP_LAMBERTIAN = 0, OP_METAL = 1, OP_DIELECTRIC = 2, OP_CHECKE
 // pixel), their 64-bit accumulators, the item counter and all queue heads/tails in SGPRs.
 // Nothing is shared between waves after the scene has been staged: no barrier, no inter-wave
 // atomic.  (A block-level pool with barriers was measured 20 % slower)
+constexpr uint32_t ring_capacity(uint32_t slots) { uint32_t r = 64; while (r < slots) r *= 2; return r; }
+
 template <uint32_t SLOTS>
 struct WavePoolLayout {
+    static constexpr uint32_t kRing     = ring_capacity(SLOTS);               // per-queue ring capacity (power of two >= SLOTS)
     static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
     static constexpr uint32_t kOffFlags = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32
-    static constexpr uint32_t kOffRing  = kOffFlags + SLOTS * 4;              // [kNumOps][SLOTS] u8 (ring capacity = SLOTS)
-    static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * SLOTS + 15) / 16) * 16;
+    static constexpr uint32_t kOffRing  = kOffFlags + SLOTS * 4;              // [kNumOps][kRing] u8
+    static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * kRing + 15) / 16) * 16;
 };
 
-template <uint32_t THREADS, uint32_t SLOTS, bool COUNT, bool HOSEK>
-__global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
+template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK>
+__global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
 {
     using Lay = WavePoolLayout<SLOTS>;
-    static_assert(SLOTS >= 64 && SLOTS <= 256 && (SLOTS & (SLOTS - 1)) == 0, "slot ids are 8 bit, ring capacity = SLOTS");
+    constexpr uint32_t RING = Lay::kRing;
+    static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 16 == 0, "slot ids are 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
     const SceneLds S = stage_scene<true>(A, smem, HOSEK);
     const uint32_t tid = threadIdx.x;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
         const uint32_t row1 = (base_ci + 1 < A.out_rows) ? abs_row(A, base_ci + 1) : row0;
 
         // all slots start in the OP_GEN queue
-        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * SLOTS + s] = (unsigned char)s; L_flags[s] = 0u; }
+        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_flags[s] = 0u; }
         if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
         uint32_t head[kNumOps], tail[kNumOps];             // wave-uniform (SGPRs)
 #pragma unroll
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
 
             // ---- pop + gather ----
             const bool has = lane < my_n;
-            const uint32_t slot = has ? (uint32_t)L_ring[my_k * SLOTS + ((my_begin + lane) & (SLOTS - 1u))] : 0u;
+            const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + ((my_begin + lane) & (RING - 1u))] : 0u;
             const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
             const uint32_t fl = L_flags[slot];
             f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));
@@ -838,13 +846,15 @@ __global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
                 const unsigned long long mk_ = __ballot(new_op == k);
-                if (new_op == k) L_ring[k * SLOTS + ((tail[k] + (uint32_t)__popcll(mk_ & lt_mask)) & (SLOTS - 1u))] = (unsigned char)slot;
+                if (new_op == k) L_ring[k * RING + ((tail[k] + (uint32_t)__popcll(mk_ & lt_mask)) & (RING - 1u))] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
             }
         }
 
         // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
-        if (lane < strip_pixels) {
+        if (A.accum) {                           // progressive mode: add the exact sums, resolve later
+            if (lane < strip_pixels * 3) A.accum[3ull * base_pix + lane] += L_acc[lane];
+        } else if (lane < strip_pixels) {
             const uint32_t rgba = pack_rgba(resolve_channel(L_acc[lane * 3 + 0], A.spp, A.flags),
                                             resolve_channel(L_acc[lane * 3 + 1], A.spp, A.flags),
                                             resolve_channel(L_acc[lane * 3 + 2], A.spp, A.flags));
@@ -852,6 +862,29 @@ __global__ __launch_bounds__(THREADS) void render_pt_pool_kernel(RenderArgs A)
         }
         work.flush(A.counters, lane);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// resolve of the progressive accumulation buffer: exact sums -> mean -> tonemap -> RGBA8
+// (the `invN * pixel` + uncharted2 tail of fsMain, wgsl:75-80)
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void resolve_accum_kernel(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels,
+                                                            uint32_t n_samples, uint32_t flags)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = pack_rgba(resolve_channel(accum[3 * i + 0], n_samples, flags), resolve_channel(accum[3 * i + 1], n_samples, flags),
+                           resolve_channel(accum[3 * i + 2], n_samples, flags));
+}
+
+hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
+                          uint32_t flags, hipStream_t stream)
+{
+    uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(resolve_accum_kernel, dim3(blocks), dim3(256), 0, stream, accum, out, n_pixels, n_samples, flags);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -910,28 +943,30 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
                  : launch_with_lds(render_pt_strip_kernel<false, false>, g, b, a, stream);
 }
 
-template <uint32_t T, uint32_t SL>
+template <uint32_t T, uint32_t SL, uint32_t MW = 1>
 static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(T);
-    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, true, true>, g, b, a, stream)
-                            : launch_with_lds(render_pt_pool_kernel<T, SL, true, false>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, false, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<T, SL, false, false>, g, b, a, stream);
+    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, false>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  128 slots x 52 B keeps a
 // wave's pool under 8 KB, so that 20 waves (the VGPR limit) still fit a CU's 160 KB of LDS;
 // measured on config 3: 256 slots -> 8 waves/CU, 1.7x slower; 64 slots -> 68 % lane use, 1.4x slower.
-static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 128, 128, 0 }, { 512, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
+static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 128, 128, 0 }, { 512, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 },
+                                           { 256, 96, 0 }, { 256, 96, 0 }, { 256, 112, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
 PoolConfig pool_config(uint32_t i)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
-                                                                                                : WavePoolLayout<256>::kBytes;
+    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 96) ? WavePoolLayout<96>::kBytes
+                            : (c.slots == 112) ? WavePoolLayout<112>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
+                                                                                                  : WavePoolLayout<256>::kBytes;
     c.lds_bytes = per_wave * (c.threads / 64);
     return c;
 }
@@ -944,6 +979,9 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
     case 2:  return launch_pool_cfg<512, 128>(a, grid_blocks, count, hosek, stream);
     case 3:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
     case 4:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
+    case 5:  return launch_pool_cfg<256, 96, 6>(a, grid_blocks, count, hosek, stream);
+    case 6:  return launch_pool_cfg<256, 96, 1>(a, grid_blocks, count, hosek, stream);
+    case 7:  return launch_pool_cfg<256, 112, 1>(a, grid_blocks, count, hosek, stream);
     default: return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
     }
 }

@@ -463,25 +463,45 @@ class Raytracer:
         self._ctx = Context(device)
         self._ctx.set_scene(self.scene_data())
         self.last_stats: Optional[dict] = None
+        self._accumulated = None        # RenderProgress (mod.rs:615-679): None = reset pending
 
     def scene_data(self) -> SceneData:
         return SceneData(self.camera.c, [s.to_c() for s in self.spheres], list(self.material_data),
                          self.global_texture_data, self.sky_state)
+
+    def _params(self, spp: int, seed: int, flags: int) -> _abi.MirtParams:
+        rp = self.render_params
+        if self.sky_state is not None:
+            flags |= _abi.MIRT_FLAG_SKY_HOSEK
+        return make_params(rp.viewport_size[0], rp.viewport_size[1], spp, mode=_abi.MIRT_MODE_PT,
+                           num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed)
+
+    def render_frame(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
+        """`Raytracer::render_frame` (mod.rs:303-351) without the wgpu draw: add
+        `num_samples_per_pixel` samples per call until `max_samples_per_pixel` is reached
+        (`RenderProgress::next_frame`, mod.rs:626-670), return the current estimate as RGBA8."""
+        smp = self.render_params.sampling
+        if self._accumulated is None:                          # first frame after a reset: clear
+            self._ctx.accum_reset(self._params(smp.num_samples_per_pixel, seed, flags))
+            self._accumulated = 0
+        if self._accumulated + smp.num_samples_per_pixel <= smp.max_samples_per_pixel:
+            self._ctx.accum_add(self._params(smp.num_samples_per_pixel, seed, flags))
+            self._accumulated += smp.num_samples_per_pixel
+        return self._ctx.accum_resolve(self._params(smp.num_samples_per_pixel, seed, flags))
+
+    def progress(self) -> float:                               # mod.rs:390-393
+        return (self._accumulated or 0) / float(self.render_params.sampling.max_samples_per_pixel)
 
     def set_render_params(self, render_params: RenderParams) -> None:   # mod.rs:353-388
         render_params.validate()
         self.render_params = render_params
         self.camera = GpuCamera.new(render_params.camera, render_params.viewport_size)
         self._ctx.set_camera(self.camera.c)
+        self._accumulated = None                               # render_progress.reset() mod.rs:385
 
     def render(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
         """All `max_samples_per_pixel` samples in one launch -> RGBA8 [h][w][4]."""
-        rp = self.render_params
-        w, h = rp.viewport_size
-        if self.sky_state is not None:
-            flags |= _abi.MIRT_FLAG_SKY_HOSEK
-        params = make_params(w, h, rp.sampling.max_samples_per_pixel, mode=_abi.MIRT_MODE_PT,
-                             num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed)
+        params = self._params(self.render_params.sampling.max_samples_per_pixel, seed, flags)
         img = self._ctx.render(params)
         self.last_stats = self._ctx.stats()
         return img
