@@ -281,6 +281,12 @@ int mirt_ctx_accum_resolve(MirtContext* ctx, const MirtParams* params, uint8_t* 
 /* Copy the raw sums to the host: pixels x 3 uint64 (the fp32-intermediate view used by tests). */
 int mirt_ctx_accum_read(MirtContext* ctx, uint64_t* out_sums, size_t out_len_u64);
 
+/* Device self-test of the arithmetic contract: the kernels' fast sqrt and reciprocal sequences
+ * (hardware seed + one fma correction) are compared with the compiler's correctly rounded IEEE
+ * expansions over ALL 2^32 binary32 bit patterns.  Writes the two mismatch counts (sqrt, 1/x);
+ * both must be 0 for the bit-parity claim to hold on this device. */
+int mirt_ctx_selftest_math(MirtContext* ctx, uint64_t out_mismatches[2]);
+
 /* One-shot convenience: create context on `device`, set scene, render to host, destroy.
  * Signature a Rust `set_data` binds when it does not keep a context. */
 int mirt_render(const MirtScene* scene, const MirtParams* params, int device,

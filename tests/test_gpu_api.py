@@ -160,3 +160,9 @@ def test_many_contexts_and_reuse(oracle):
                 img = ctx.render(p)
             assert_images_equal(img, want, "reuse")
             assert ctx.stats()["launches"] == 70
+
+
+def test_fast_sqrt_rcp_are_correctly_rounded(gpu_ctx):
+    """The kernels' 5-instruction sqrt and 3-instruction reciprocal must equal the IEEE results for
+    EVERY binary32 bit pattern on this device — the bit-parity claim against the CPU rests on it."""
+    assert gpu_ctx.selftest_math() == (0, 0)

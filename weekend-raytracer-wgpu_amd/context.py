@@ -131,6 +131,12 @@ class Context:
         check(lib().mirt_ctx_accum_read(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
+    def selftest_math(self) -> tuple:
+        """(sqrt mismatches, reciprocal mismatches) of the fast sequences vs IEEE over all 2^32 floats."""
+        out = (C.c_uint64 * 2)()
+        check(lib().mirt_ctx_selftest_math(self._h, out))
+        return int(out[0]), int(out[1])
+
     def synchronize(self) -> None:
         check(lib().mirt_ctx_synchronize(self._h))
 

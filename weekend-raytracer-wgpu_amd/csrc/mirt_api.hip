@@ -652,6 +652,20 @@ int mirt_ctx_accum_read(MirtContext* c, uint64_t* out_sums, size_t out_len_u64)
     return MIRT_OK;
 }
 
+int mirt_ctx_selftest_math(MirtContext* c, uint64_t out[2])
+{
+    if (!c || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(mirt::launch_selftest_math(c->d_counters, c->stream));
+    unsigned long long h[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = h[0];
+    out[1] = h[1];
+    return MIRT_OK;
+}
+
 int mirt_render(const MirtScene* scene, const MirtParams* params, int device, uint8_t* out, size_t out_len)
 {
     MirtContext* c = nullptr;

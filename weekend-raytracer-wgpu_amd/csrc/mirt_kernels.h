@@ -88,6 +88,7 @@ PoolConfig pool_config(uint32_t i);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream);
 hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
                           uint32_t flags, hipStream_t stream);
+hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t stream);
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream);
 size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek);
 

@@ -353,7 +353,7 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
                          Work<COUNT>& work)
 {
     const float a = dot(rd, rd);
-    const float inv_a = 1.0f / a;
+    const float inv_a = rcp_(a);
     float closest = kMaxT;
     int best = -1;
     if (alive) { work.add(kCntRays); work.add(kCntTests, n_spheres); }
@@ -433,7 +433,7 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
     const float lx = sc.c * sqrt_r2;
     const float ly = sc.s * sqrt_r2;
     const float sg = (n.z >= 0.0f) ? 1.0f : -1.0f;
-    const float aa = -1.0f / (sg + n.z);
+    const float aa = -rcp_(sg + n.z);                  // -(1/x) == -1/x exactly
     const float bb = n.x * n.y * aa;
     const f3 U = mk(fma_(sg * n.x, n.x * aa, 1.0f), sg * bb, -(sg * n.x));
     const f3 V = mk(bb, fma_(n.y, n.y * aa, sg), -n.y);
@@ -553,7 +553,7 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
     float m = (float)((double)sum / denom);
     if (!(flags & MIRT_FLAG_NO_TONEMAP)) {   // uncharted2 wgsl:83-92
         const float curr = uncharted2_tonemap(0.246f * m);
-        const float white = 1.0f / uncharted2_tonemap(11.2f);
+        const float white = rcp_(uncharted2_tonemap(11.2f));
         m = white * curr;
     }
     if (!(flags & MIRT_FLAG_NO_SRGB))        // the Bgra8UnormSrgb surface's transfer curve
@@ -862,6 +862,32 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         }
         work.flush(A.counters, lane);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// self-test: the fast sqrt_/rcp_ against the IEEE expansions over ALL 2^32 binary32 patterns
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void selftest_math_kernel(unsigned long long* mismatches)
+{
+    unsigned long long bad_sqrt = 0, bad_rcp = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = from_bits((uint32_t)i);
+        bad_sqrt += bits(sqrt_(x)) != bits(sqrt_ieee(x));
+        bad_rcp += bits(rcp_(x)) != bits(rcp_ieee(x));
+    }
+    bad_sqrt = wave_sum_u64(bad_sqrt);
+    bad_rcp = wave_sum_u64(bad_rcp);
+    if ((threadIdx.x & 63u) == 0) {
+        if (bad_sqrt) atomicAdd(&mismatches[0], bad_sqrt);
+        if (bad_rcp) atomicAdd(&mismatches[1], bad_rcp);
+    }
+}
+
+hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_math_kernel, dim3(4096), dim3(256), 0, stream, d_mismatches);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
