@@ -1,0 +1,172 @@
+//! Raw bindings to `include/mirt.h`.  SOURCE ONLY — never compiled in this repository (no Rust
+//! toolchain in the build environment); kept in sync with the header by hand and mirrored, field
+//! for field, by the ctypes binding (`weekend-raytracer-wgpu_amd/_abi.py`) whose layout IS tested.
+//!
+//! The wire structs are byte-identical to the reference crate's own `#[repr(C)]` types
+//! (`Sphere`, `GpuMaterial`, `TextureDescriptor`, `GpuCamera`, `GpuSkyState`), so a host that
+//! already has those can pass pointers to them instead of these mirrors.
+#![allow(non_camel_case_types)]
+
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtSphere {
+    pub center: [f32; 4],
+    pub radius: f32,
+    pub material_idx: u32,
+    pub _pad: [u32; 2],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtTextureDescriptor {
+    pub width: u32,
+    pub height: u32,
+    pub offset: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtMaterial {
+    pub id: u32,
+    pub desc1: MirtTextureDescriptor,
+    pub desc2: MirtTextureDescriptor,
+    pub x: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtGpuCamera {
+    pub eye: [f32; 3],
+    pub _padding1: f32,
+    pub horizontal: [f32; 3],
+    pub _padding2: f32,
+    pub vertical: [f32; 3],
+    pub _padding3: f32,
+    pub u: [f32; 3],
+    pub _padding4: f32,
+    pub v: [f32; 3],
+    pub lens_radius: f32,
+    pub lower_left_corner: [f32; 3],
+    pub _padding5: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct MirtSkyState {
+    pub params: [f32; 27],
+    pub radiances: [f32; 3],
+    pub _padding: [u32; 2],
+    pub sun_direction: [f32; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtCamera {
+    pub eye_pos: [f32; 3],
+    pub eye_dir: [f32; 3],
+    pub up: [f32; 3],
+    pub vfov_radians: f32,
+    pub aperture: f32,
+    pub focus_distance: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtSamplingParams {
+    pub max_samples_per_pixel: u32,
+    pub num_samples_per_pixel: u32,
+    pub num_bounces: u32,
+}
+
+#[repr(C)]
+pub struct MirtScene {
+    pub camera: *const MirtGpuCamera,
+    pub spheres: *const MirtSphere,
+    pub n_spheres: u32,
+    pub materials: *const MirtMaterial,
+    pub n_materials: u32,
+    pub texels: *const [f32; 3],
+    pub n_texels: u64,
+    pub sky: *const MirtSkyState,
+}
+
+pub const MIRT_MODE_PARITY: u32 = 0;
+pub const MIRT_MODE_PT: u32 = 1;
+pub const MIRT_FLAG_SKY_HOSEK: u32 = 1 << 0;
+pub const MIRT_FLAG_NO_TONEMAP: u32 = 1 << 1;
+pub const MIRT_FLAG_NO_SRGB: u32 = 1 << 2;
+pub const MIRT_FLAG_COUNT_WORK: u32 = 1 << 3;
+pub const MIRT_FLAG_KERNEL_STRIP: u32 = 1 << 4;
+pub const MIRT_FLAG_KERNEL_POOL: u32 = 1 << 5;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtParams {
+    pub width: u32,
+    pub height: u32,
+    pub spp: u32,
+    pub num_bounces: u32,
+    pub mode: u32,
+    pub flags: u32,
+    pub seed: u64,
+    pub row_begin: u32,
+    pub row_end: u32,
+    pub tile_rows: u32,
+    pub n_parts: u32,
+    pub part: u32,
+    pub sample_begin: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct MirtStats {
+    pub kernel_ms: f64,
+    pub kernel_ms_total: f64,
+    pub launches: u64,
+    pub samples: u64,
+    pub rays: u64,
+    pub sphere_tests: u64,
+    pub roots: u64,
+    pub hits: u64,
+    pub scatter: [u64; 5],
+    pub sky_misses: u64,
+    pub lane_iterations: u64,
+    pub wave_iterations: u64,
+}
+
+#[repr(C)]
+pub struct MirtContext {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn mirt_version() -> u32;
+    pub fn mirt_last_error() -> *const c_char;
+    pub fn mirt_status_string(status: c_int) -> *const c_char;
+    pub fn mirt_validate_render_params(camera: *const MirtCamera, sampling: *const MirtSamplingParams, viewport_w: u32, viewport_h: u32) -> c_int;
+    pub fn mirt_camera_new(camera: *const MirtCamera, viewport_w: u32, viewport_h: u32, out: *mut MirtGpuCamera) -> c_int;
+    pub fn mirt_camera_from_fly_pose(position: *const f32, yaw_radians: f32, pitch_radians: f32, vfov_degrees: f32, aperture: f32, focus_distance: f32, out: *mut MirtCamera) -> c_int;
+    pub fn mirt_degrees_to_radians(degrees: f32) -> f32;
+    pub fn mirt_radians_to_degrees(radians: f32) -> f32;
+    pub fn mirt_params_out_rows(params: *const MirtParams) -> u32;
+    pub fn mirt_params_out_row_index(params: *const MirtParams, i: u32) -> u32;
+    pub fn mirt_ctx_create(device: c_int, out: *mut *mut MirtContext) -> c_int;
+    pub fn mirt_ctx_destroy(ctx: *mut MirtContext);
+    pub fn mirt_ctx_set_scene(ctx: *mut MirtContext, scene: *const MirtScene) -> c_int;
+    pub fn mirt_ctx_set_camera(ctx: *mut MirtContext, camera: *const MirtGpuCamera) -> c_int;
+    pub fn mirt_ctx_render(ctx: *mut MirtContext, params: *const MirtParams, out_rgba8: *mut u8, out_len: usize) -> c_int;
+    pub fn mirt_ctx_render_device(ctx: *mut MirtContext, params: *const MirtParams, d_out_rgba8: *mut c_void, out_len: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn mirt_ctx_synchronize(ctx: *mut MirtContext) -> c_int;
+    pub fn mirt_ctx_get_stats(ctx: *mut MirtContext, out: *mut MirtStats) -> c_int;
+    pub fn mirt_ctx_accum_reset(ctx: *mut MirtContext, params: *const MirtParams) -> c_int;
+    pub fn mirt_ctx_accum_add(ctx: *mut MirtContext, params: *const MirtParams, hip_stream: *mut c_void) -> c_int;
+    pub fn mirt_ctx_accum_samples(ctx: *const MirtContext) -> u32;
+    pub fn mirt_ctx_accum_resolve(ctx: *mut MirtContext, params: *const MirtParams, out_rgba8: *mut u8, out_len: usize) -> c_int;
+    pub fn mirt_ctx_accum_read(ctx: *mut MirtContext, out_sums: *mut u64, out_len_u64: usize) -> c_int;
+    pub fn mirt_ctx_selftest_math(ctx: *mut MirtContext, out_mismatches: *mut u64) -> c_int;
+    pub fn mirt_render(scene: *const MirtScene, params: *const MirtParams, device: c_int, out_rgba8: *mut u8, out_len: usize) -> c_int;
+    pub fn mirt_rgba8_to_rgb8(rgba: *const u8, n_pixels: usize, rgb: *mut u8) -> c_int;
+    pub fn mirt_ctx_deinterleave_device(ctx: *mut MirtContext, params: *const MirtParams, d_parts: *const c_void, part_stride: usize, d_out_rgba8: *mut c_void, out_len: usize, hip_stream: *mut c_void) -> c_int;
+}
