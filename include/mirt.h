@@ -131,7 +131,8 @@ enum {
     /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the
      * pooled kernel (paths queued by material in LDS) when spp >= 48, else the strip kernel. */
     MIRT_FLAG_KERNEL_STRIP   = 1u << 4, /* force the strip kernel (wave = 64 samples of one pixel) */
-    MIRT_FLAG_KERNEL_POOL    = 1u << 5  /* force the pooled kernel */
+    MIRT_FLAG_KERNEL_POOL    = 1u << 5, /* force the pooled kernel */
+    MIRT_FLAG_NO_GRID        = 1u << 6  /* many-sphere scenes: scan the flat sphere list instead of the uniform grid */
 };
 
 /* What one render call computes.  The image is `width x height`; this call renders the rows

@@ -100,6 +100,7 @@ pub const MIRT_FLAG_NO_SRGB: u32 = 1 << 2;
 pub const MIRT_FLAG_COUNT_WORK: u32 = 1 << 3;
 pub const MIRT_FLAG_KERNEL_STRIP: u32 = 1 << 4;
 pub const MIRT_FLAG_KERNEL_POOL: u32 = 1 << 5;
+pub const MIRT_FLAG_NO_GRID: u32 = 1 << 6;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

@@ -266,3 +266,58 @@ def test_raytracer_render_frame_progression(oracle):
     assert rt.progress() == 0.0
     assert_images_equal(rt.render_frame(), oracle.render(sd, m.make_params(64, 40, 4, mode=m.MIRT_MODE_PT, num_bounces=8)), "after reset")
     rt.close()
+
+
+def _sphere_soup(rng, n, spread, r_lo, r_hi, n_big=2):
+    T = m.Texture
+    mats = [m.Material.Lambertian(T.new_from_color(rng.random(3))), m.Material.Metal(T.new_from_color(0.5 + 0.5 * rng.random(3)), 0.3),
+            m.Material.Dielectric(1.5), m.Material.Checkerboard(even=T.new_from_color((0.2, 0.3, 0.1)), odd=T.new_from_color((0.9, 0.9, 0.9)))]
+    gm, tex = m.flatten_materials(mats)
+    spheres = [m.Sphere.new((0.0, -1000.0, 0.0), 1000.0, 3).to_c()]
+    for _ in range(n_big):
+        spheres.append(m.Sphere.new(rng.normal(size=3) * spread * 0.3 + (0, 1.5, 0), 1.5, int(rng.integers(0, 3))).to_c())
+    for _ in range(n):
+        c = rng.normal(size=3) * spread
+        c[1] = abs(c[1]) * 0.3 + 0.1
+        spheres.append(m.Sphere.new(c, float(rng.uniform(r_lo, r_hi)), int(rng.integers(0, 4))).to_c())
+    return spheres, gm, tex
+
+
+@pytest.mark.parametrize("seed,n,spread", [(0, 40, 3.0), (1, 200, 6.0), (2, 484, 8.0), (3, 1000, 5.0), (4, 64, 0.5)])
+def test_grid_nearest_hit_equals_flat_scan(gpu_ctx, oracle, seed, n, spread):
+    """Many-sphere scenes go through the uniform grid (csrc nearest_hit_grid).  The image must equal the
+    oracle's flat scan bit for bit — overlapping, nested and duplicated spheres included (duplicates force
+    the index tie-break) — and must equal the library's own flat-scan build (MIRT_FLAG_NO_GRID)."""
+    rng = np.random.default_rng(1000 + seed)
+    spheres, gm, tex = _sphere_soup(rng, n, spread, 0.05, 0.35)
+    spheres += spheres[5:15]                               # exact duplicates, later in the list
+    w, h, spp = 96, 54, 8
+    fc = m.FlyCameraController(np.float32([spread * 1.5, 1.5 + seed, spread * 1.2]), m.Angle.degrees(215.0 + 7 * seed),
+                               m.Angle.degrees(-12.0), 40.0, 0.05, float(spread * 1.8))
+    sd = m.SceneData(m.GpuCamera.new(fc.renderer_camera(), (w, h)).c, spheres, gm, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=LINEAR)
+    want = oracle.render(sd, p)
+    got_grid = gpu_ctx.render(p)
+    t_grid = gpu_ctx.stats()["kernel_ms"]
+    got_flat = gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=LINEAR | m.MIRT_FLAG_NO_GRID))
+    t_flat = gpu_ctx.stats()["kernel_ms"]
+    assert_images_equal(got_flat, want, "flat scan")
+    assert_images_equal(got_grid, want, f"grid ({t_grid:.2f} ms vs flat {t_flat:.2f} ms)")
+    print(f"grid {t_grid:.2f} ms, flat {t_flat:.2f} ms")
+
+
+def test_grid_with_rays_parallel_to_axes(gpu_ctx, oracle):
+    """Axis-aligned rays (zero direction components) through the grid: the DDA's 1/0 handling."""
+    rng = np.random.default_rng(77)
+    spheres, gm, tex = _sphere_soup(rng, 150, 4.0, 0.1, 0.3)
+    cam = m._abi.MirtGpuCamera()
+    cam.eye[:] = [0.0, 0.4, 12.0]
+    cam.horizontal[:] = [8.0, 0.0, 0.0]
+    cam.vertical[:] = [0.0, 0.0, 0.0]                     # every ray has d.y == 0 exactly ... and the centre column d.x == 0
+    cam.u[:] = [1.0, 0.0, 0.0]
+    cam.v[:] = [0.0, 1.0, 0.0]
+    cam.lower_left_corner[:] = [-4.0, 0.4, 0.0]
+    sd = m.SceneData(cam, spheres, gm, tex)
+    p = m.make_params(65, 3, 8, mode=m.MIRT_MODE_PT, num_bounces=4, flags=LINEAR)
+    assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), "axis-parallel rays")

@@ -16,6 +16,7 @@ MIRT_FLAG_NO_SRGB = 1 << 2
 MIRT_FLAG_COUNT_WORK = 1 << 3
 MIRT_FLAG_KERNEL_STRIP = 1 << 4
 MIRT_FLAG_KERNEL_POOL = 1 << 5
+MIRT_FLAG_NO_GRID = 1 << 6
 
 MIRT_OK = 0
 STATUS = {

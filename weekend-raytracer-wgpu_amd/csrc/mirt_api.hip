@@ -7,6 +7,7 @@
 // (-ffp-contract=off applies to host code too).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -90,6 +91,85 @@ V3 scale3(float s, V3 a) { return V3{ s * a.x, s * a.y, s * a.z }; }
 V3 add3(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
 V3 sub3(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
 
+// Build the uniform grid of mirt_kernels.h over the spheres of a many-sphere scene.  Returns an empty
+// blob when a grid would not help (few spheres, or nothing small enough to bin).
+std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n)
+{
+    std::vector<unsigned char> blob;
+    if (n < mirt::kGridMinSpheres || n > 65535u) return blob;
+    std::vector<float> radii(n);
+    for (uint32_t i = 0; i < n; ++i) radii[i] = std::fabs(sph[i].radius);
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float r_med = sorted[n / 2];
+    if (!(r_med > 0.0f) || !std::isfinite(r_med)) return blob;
+    // spheres up to 4 median radii go into the grid; the rest (ground planes, hero spheres) are tested for every ray
+    std::vector<uint16_t> big, small;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool finite = std::isfinite(sph[i].center[0]) && std::isfinite(sph[i].center[1]) && std::isfinite(sph[i].center[2]) && std::isfinite(radii[i]);
+        if (!finite || radii[i] > 4.0f * r_med) { big.push_back((uint16_t)i); continue; }
+        small.push_back((uint16_t)i);
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], (double)sph[i].center[k] - radii[i]);
+            hi[k] = std::max(hi[k], (double)sph[i].center[k] + radii[i]);
+        }
+    }
+    if (small.size() < mirt::kGridMinSpheres / 2 || big.size() > 64) return blob;
+    double cell = 4.0 * r_med;                                   // a small sphere then spans at most 3 cells per axis
+    uint32_t dims[3];
+    for (;;) {
+        uint64_t total = 1;
+        for (int k = 0; k < 3; ++k) { dims[k] = (uint32_t)std::max(1.0, std::ceil((hi[k] - lo[k]) / cell + 1e-6)); total *= dims[k]; }
+        if (total <= mirt::kGridMaxCells) break;
+        cell *= 1.26;
+    }
+    const double eps = 1e-3 * cell;                               // enlargement that makes the binning conservative
+    const uint32_t ncells = dims[0] * dims[1] * dims[2];
+    std::vector<std::vector<uint16_t>> lists(ncells);
+    for (uint16_t i : small) {
+        int c0[3], c1[3];
+        for (int k = 0; k < 3; ++k) {
+            c0[k] = (int)std::floor(((double)sph[i].center[k] - radii[i] - eps - lo[k]) / cell);
+            c1[k] = (int)std::floor(((double)sph[i].center[k] + radii[i] + eps - lo[k]) / cell);
+            c0[k] = std::max(0, std::min((int)dims[k] - 1, c0[k]));
+            c1[k] = std::max(0, std::min((int)dims[k] - 1, c1[k]));
+        }
+        for (int z = c0[2]; z <= c1[2]; ++z)
+            for (int y = c0[1]; y <= c1[1]; ++y)
+                for (int x = c0[0]; x <= c1[0]; ++x) lists[((size_t)z * dims[1] + y) * dims[0] + x].push_back(i);   // ascending ids
+    }
+    size_t n_items = 0;
+    for (auto& l : lists) n_items += l.size();
+    if (n_items > 65535u) return blob;                            // cell_start is 16 bit
+    mirt::GridHeader h{};
+    for (int k = 0; k < 3; ++k) {
+        h.org[k] = (float)lo[k];
+        h.cell[k] = (float)cell;
+        h.inv_cell[k] = (float)(1.0 / cell);
+        h.dims[k] = dims[k];
+    }
+    h.n_big = (uint32_t)big.size();
+    const size_t hdr_u16 = sizeof(mirt::GridHeader) / 2;
+    h.off_big = (uint32_t)hdr_u16;
+    h.off_start = h.off_big + (uint32_t)big.size();
+    h.off_items = h.off_start + ncells + 1;
+    size_t total_u16 = (size_t)h.off_items + n_items;
+    total_u16 = (total_u16 + 7) & ~size_t(7);
+    h.total_bytes = (uint32_t)(total_u16 * 2);
+    blob.assign(h.total_bytes, 0);
+    uint16_t* u = reinterpret_cast<uint16_t*>(blob.data());
+    std::memcpy(blob.data(), &h, sizeof h);
+    for (size_t i = 0; i < big.size(); ++i) u[h.off_big + i] = big[i];
+    uint32_t pos = 0;
+    for (uint32_t c = 0; c < ncells; ++c) {
+        u[h.off_start + c] = (uint16_t)pos;
+        for (uint16_t id : lists[c]) u[h.off_items + pos++] = id;
+    }
+    u[h.off_start + ncells] = (uint16_t)pos;
+    return blob;
+}
+
 template <typename T>
 int ensure_capacity(T** ptr, size_t* cap, size_t need)
 {
@@ -132,6 +212,9 @@ struct MirtContext {
     MirtMaterial*         d_mats = nullptr;
     mirt::PreparedMaterial* d_pmats = nullptr;
     size_t cap_pmats = 0;
+    unsigned char* d_grid = nullptr;        // uniform grid blob (many-sphere scenes), see build_grid
+    size_t cap_grid = 0;
+    uint32_t grid_bytes = 0;
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;
     size_t cap_spheres = 0, cap_mats = 0, cap_texels = 0;
@@ -305,7 +388,7 @@ void mirt_ctx_destroy(MirtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_texels);
+    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
@@ -394,6 +477,14 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_pmats, pmats.data(), pmats.size() * sizeof(mirt::PreparedMaterial), hipMemcpyHostToDevice));
     if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    {
+        const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres);
+        c->grid_bytes = (uint32_t)grid.size();
+        if (!grid.empty()) {
+            if ((rc = ensure_capacity(&c->d_grid, &c->cap_grid, grid.size())) != MIRT_OK) return rc;
+            HIP_TRY(hipMemcpy(c->d_grid, grid.data(), grid.size(), hipMemcpyHostToDevice));
+        }
+    }
     c->have_sky = s->sky != nullptr;
     if (s->sky) HIP_TRY(hipMemcpy(c->d_sky, s->sky, sizeof(MirtSkyState), hipMemcpyHostToDevice));
     c->n_spheres = s->n_spheres;
@@ -493,7 +584,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
-    a.lds_bytes = (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
+    // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
+    // the counting build keeps the reference's flat scan so that its work counters stay comparable)
+    const bool use_grid = pt && !pool && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID) &&
+                          scene_lds + c->grid_bytes <= (size_t)c->lds_per_block;
+    a.grid = use_grid ? c->d_grid : nullptr;
+    a.grid_bytes = use_grid ? c->grid_bytes : 0u;
+    a.lds_bytes = (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0) + a.grid_bytes);
 
     uint32_t blocks;
     if (pool) {
@@ -518,7 +615,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
     else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, stream));
-    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, stream));
+    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     c->ev_used = ev + 1;
     c->stats_counted = count;

@@ -37,6 +37,26 @@ struct PreparedMaterial {
 static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
 constexpr uint32_t kMatTex1Is1x1 = 1u, kMatTex2Is1x1 = 2u;
 
+// Uniform grid over the small spheres of a many-sphere scene (>= kGridMinSpheres): the nearest-hit scan
+// visits only the cells a ray crosses (3D-DDA) plus a short list of "big" spheres.  The grid is
+// CONSERVATIVE (every sphere is listed in all cells its slightly enlarged bounding box touches) and the
+// hit rule breaks ties by sphere index, so the result is identical to the reference's flat scan.
+struct GridHeader {
+    float    org[3];        // lower corner
+    float    cell[3];       // cell size per axis
+    float    inv_cell[3];
+    uint32_t dims[3];
+    uint32_t n_big;         // spheres tested for every ray (too large for the grid)
+    uint32_t off_big;       // offsets in uint16 units from the start of the blob
+    uint32_t off_start;     // [ncells + 1] first item of each cell
+    uint32_t off_items;     // sphere ids, ascending within a cell
+    uint32_t total_bytes;   // multiple of 16
+    uint32_t _pad[3];
+};
+static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte copies");
+constexpr uint32_t kGridMinSpheres = 32;
+constexpr uint32_t kGridMaxCells   = 8192;
+
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
@@ -61,6 +81,8 @@ struct RenderArgs {
     const MirtSkyState*     sky;
     uint32_t*               out;           // compact RGBA8, one u32 per pixel
     unsigned long long*     counters;      // [kNumCounters], COUNT builds only
+    const unsigned char*    grid;          // nullable: GridHeader + lists (strip kernel, GRID build)
+    uint32_t                grid_bytes;
     uint32_t*               work_counter;  // dynamic work dispenser, zeroed before every launch
     unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;
@@ -81,7 +103,7 @@ struct DeinterleaveArgs {
 
 // launchers (mirt_kernels.hip)
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream);
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, hipStream_t stream);
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i);

@@ -380,6 +380,123 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
     return best;
 }
 
+
+MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
+
+// ---- nearest hit through the uniform grid (many-sphere scenes) ----
+//
+// Equivalence with the flat scan (nearest_hit above).  For one sphere let f = its first root above
+// MIN_T (t0 if t0 > MIN_T, else t1 if t1 > MIN_T).  The scan replaces `closest` exactly when
+// f < closest, so whatever the visiting order the result is min f over the spheres, and on equal f
+// the flat scan keeps the LOWER index (strict `<`).  Here spheres are visited in cell order and
+// possibly several times, so the update rule carries the tie-break explicitly.  A cell walk may
+// stop as soon as closest <= the parameter at which the ray leaves the current cell: any sphere
+// with a smaller f is intersected inside a cell already visited, and is listed there because every
+// sphere is registered in all cells its (slightly enlarged) bounding box overlaps.
+struct GridLds {
+    const GridHeader*     h;
+    const unsigned short* big;
+    const unsigned short* start;
+    const unsigned short* items;
+};
+
+MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best)
+{
+    const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
+    const f3 oc = ro - mk(s4.x, s4.y, s4.z);
+    const float b = dot(oc, rd);
+    const float cq = dot(oc, oc) - s4.w;
+    const float disc = fma_(b, b, -(a * cq));
+    if (alive && disc > 0.0f) {
+        const float sq = sqrt_(disc);
+        const float t0 = (-b - sq) * inv_a;
+        const float t1 = (-b + sq) * inv_a;
+        const bool first = t0 > kMinT;
+        const float f = first ? t0 : t1;                          // first root above MIN_T
+        const bool valid = first || (t1 > kMinT);
+        const bool better = (f < closest) || (f == closest && (int)i < best);
+        if (valid && better) { closest = f; best = (int)i; }
+    }
+}
+
+MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool alive, float& closest_out)
+{
+    const float a = dot(rd, rd);
+    const float inv_a = rcp_(a);
+    float closest = kMaxT;
+    int best = -1;
+    const GridHeader& H = *G.h;
+    for (uint32_t j = 0; j < H.n_big; ++j) test_sphere(S, G.big[j], ro, rd, a, inv_a, alive, closest, best);
+
+    // clip the ray against the grid's box
+    const f3 org = mk(H.org[0], H.org[1], H.org[2]);
+    const f3 cell = mk(H.cell[0], H.cell[1], H.cell[2]);
+    const f3 inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
+    const int dx = (int)H.dims[0], dy = (int)H.dims[1], dz = (int)H.dims[2];
+    const f3 hi = mk(fma_((float)dx, cell.x, org.x), fma_((float)dy, cell.y, org.y), fma_((float)dz, cell.z, org.z));
+    const float kHuge = 3.0e38f;
+    const f3 inv_d = mk(rd.x != 0.0f ? rcp_(rd.x) : kHuge, rd.y != 0.0f ? rcp_(rd.y) : kHuge, rd.z != 0.0f ? rcp_(rd.z) : kHuge);
+    float tmin = 0.0f, tmax = kMaxT;
+    bool inside = alive;
+    {
+        const float o[3] = { ro.x, ro.y, ro.z }, d[3] = { rd.x, rd.y, rd.z }, id[3] = { inv_d.x, inv_d.y, inv_d.z };
+        const float lo3[3] = { org.x, org.y, org.z }, hi3[3] = { hi.x, hi.y, hi.z };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (d[k] != 0.0f) {
+                const float ta = (lo3[k] - o[k]) * id[k], tb = (hi3[k] - o[k]) * id[k];
+                tmin = max_(tmin, (ta < tb) ? ta : tb);
+                tmax = (((ta < tb) ? tb : ta) < tmax) ? ((ta < tb) ? tb : ta) : tmax;
+            } else {
+                inside = inside && (o[k] >= lo3[k]) && (o[k] <= hi3[k]);
+            }
+        }
+    }
+    // a little slack on both ends: the walk below is clamped to the grid anyway
+    bool walking = inside && (tmin <= tmax) && (tmin < closest);
+    const f3 p0 = fma3(tmin, rd, ro);
+    int cx = (int)((p0.x - org.x) * inv_cell.x), cy = (int)((p0.y - org.y) * inv_cell.y), cz = (int)((p0.z - org.z) * inv_cell.z);
+    cx = cx < 0 ? 0 : (cx >= dx ? dx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= dz ? dz - 1 : cz);
+    const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
+    // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
+    float tx = rd.x != 0.0f ? (fma_((float)(cx + (sx > 0 ? 1 : 0)), cell.x, org.x) - ro.x) * inv_d.x : kHuge;
+    float ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
+    float tz = rd.z != 0.0f ? (fma_((float)(cz + (sz > 0 ? 1 : 0)), cell.z, org.z) - ro.z) * inv_d.z : kHuge;
+    const float ddx = rd.x != 0.0f ? abs_(cell.x * inv_d.x) : kHuge;
+    const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
+    const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
+
+    while (__ballot(walking)) {
+        uint32_t first = 0, count = 0;
+        if (walking) {
+            const uint32_t c = (uint32_t)((cz * dy + cy) * dx + cx);
+            first = G.start[c];
+            count = (uint32_t)G.start[c + 1] - first;
+        }
+        for (uint32_t n = 0; __ballot(n < count); ++n) {
+            const bool on = n < count;
+            const uint32_t i = on ? (uint32_t)G.items[first + n] : 0u;
+            test_sphere(S, i, ro, rd, a, inv_a, on, closest, best);
+        }
+        if (walking) {
+            const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
+            if (closest <= t_exit || t_exit > tmax) {
+                walking = false;                               // nearest hit is final, or the ray left the grid
+            } else if (tx <= ty && tx <= tz) {
+                cx += sx; tx += ddx; walking = (cx >= 0) && (cx < dx);
+            } else if (ty <= tz) {
+                cy += sy; ty += ddy; walking = (cy >= 0) && (cy < dy);
+            } else {
+                cz += sz; tz += ddz; walking = (cz >= 0) && (cz < dz);
+            }
+        }
+    }
+    closest_out = closest;
+    return best;
+}
+
 MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
 {
     const float r = pow_pos(rng.next(), 0.33333f);
@@ -391,8 +508,6 @@ MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
 }
 
 MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
-
-MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
 
 // Albedo of texture k of a material at a hit with outward normal n: sphereIntersection's (u,v)
 // (wgsl:434-437) fed to textureLookup (wgsl:377-387).
@@ -567,11 +682,23 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
 // render_pt_strip — lane = sample of one pixel, per-lane material switch
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT, bool HOSEK>
+template <bool COUNT, bool HOSEK, bool GRID>
 __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const SceneLds S = stage_scene<true>(A, smem, HOSEK);
+    GridLds G{};
+    if constexpr (GRID) {                                  // stage the grid behind the scene tables
+        unsigned char* gdst = smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK);
+        for (uint32_t i = threadIdx.x; i < A.grid_bytes / 16; i += blockDim.x)
+            reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(A.grid)[i];
+        __syncthreads();
+        G.h = reinterpret_cast<const GridHeader*>(gdst);
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(gdst);
+        G.big = base + G.h->off_big;
+        G.start = base + G.h->off_start;
+        G.items = base + G.h->off_items;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t npix = A.out_rows * A.width;
     const CamRegs C = load_camera(S, A);
@@ -609,7 +736,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
                         if (alive) work.add(kCntLaneIters);
                     }
                     float closest;
-                    const int best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
+                    int best;
+                    if constexpr (GRID) best = nearest_hit_grid(S, G, ro, rd, alive, closest);
+                    else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
                     if (alive) {
                         if (best >= 0) {
                             work.add(kCntHits);
@@ -959,14 +1088,16 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t 
     return launch_with_lds(render_parity_kernel, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const dim3 g(grid_blocks), b(kBlockThreads);
-    if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true>, g, b, a, stream)
-                            : launch_with_lds(render_pt_strip_kernel<true, false>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_strip_kernel<false, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_strip_kernel<false, false>, g, b, a, stream);
+    if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
+                            : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
+    if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true>, g, b, a, stream)
+                               : launch_with_lds(render_pt_strip_kernel<false, false, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, false>, g, b, a, stream)
+                 : launch_with_lds(render_pt_strip_kernel<false, false, false>, g, b, a, stream);
 }
 
 template <uint32_t T, uint32_t SL, uint32_t MW = 1>
