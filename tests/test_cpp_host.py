@@ -55,3 +55,18 @@ def test_cpp_layer_set_data_matches_oracle(ppms, tmp_path, oracle):
     got = np.fromfile(out, dtype=np.uint8).reshape(h, w, 4)
     want = oracle.render(layer_scene_data(w, h), m.make_params(w, h, spp))
     assert_images_equal(got, want, "C++ Layer::set_data")
+
+
+@pytest.mark.gpu
+def test_cpp_raytracer_progressive_frames_match_oracle(ppms, tmp_path, oracle):
+    """C++ Raytracer::render_frame: 4 progressive frames of 4 spp of the main.rs scene == 16 spp in one go."""
+    from helpers import scene_data
+    out = tmp_path / "pt.rgba"
+    w, h = 96, 54
+    r = subprocess.run([str(DEMO), "--pt", ppms["moon"], ppms["earthmap"], str(w), str(h), "4", "16", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert r.stdout.startswith("pt: 4 frames, progress 1.00")
+    got = np.fromfile(out, dtype=np.uint8).reshape(h, w, 4)
+    want = oracle.render(scene_data("main_rs_scene", w, h), m.make_params(w, h, 16, mode=m.MIRT_MODE_PT, num_bounces=8))
+    assert_images_equal(got, want, "C++ Raytracer progressive")

@@ -1111,19 +1111,18 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  128 slots x 52 B keeps a
-// wave's pool under 8 KB, so that 20 waves (the VGPR limit) still fit a CU's 160 KB of LDS;
-// measured on config 3: 256 slots -> 8 waves/CU, 1.7x slower; 64 slots -> 68 % lane use, 1.4x slower.
-static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 128, 128, 0 }, { 512, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 },
-                                           { 256, 96, 0 }, { 256, 96, 0 }, { 256, 112, 0 } };
+// wave's pool under 8 KB, so that 20 waves (the VGPR limit) still fit a CU's 160 KB of LDS.
+// Measured on config 3: 64 slots -> 68 % lane use, 1.4x slower; 256 slots -> 8 waves
+// per CU, 1.7x slower; 96 slots at 6 waves per SIMD (80 VGPRs, spills) -> same speed.
+static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
 PoolConfig pool_config(uint32_t i)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 96) ? WavePoolLayout<96>::kBytes
-                            : (c.slots == 112) ? WavePoolLayout<112>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
-                                                                                                  : WavePoolLayout<256>::kBytes;
+    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
+                                                                                                : WavePoolLayout<256>::kBytes;
     c.lds_bytes = per_wave * (c.threads / 64);
     return c;
 }
@@ -1132,13 +1131,8 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     switch (cfg) {
-    case 1:  return launch_pool_cfg<128, 128>(a, grid_blocks, count, hosek, stream);
-    case 2:  return launch_pool_cfg<512, 128>(a, grid_blocks, count, hosek, stream);
-    case 3:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
-    case 4:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
-    case 5:  return launch_pool_cfg<256, 96, 6>(a, grid_blocks, count, hosek, stream);
-    case 6:  return launch_pool_cfg<256, 96, 1>(a, grid_blocks, count, hosek, stream);
-    case 7:  return launch_pool_cfg<256, 112, 1>(a, grid_blocks, count, hosek, stream);
+    case 1:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
+    case 2:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
     default: return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
     }
 }

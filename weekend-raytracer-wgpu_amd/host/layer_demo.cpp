@@ -3,6 +3,8 @@
 //
 //   layer_demo --host-only MOON.ppm EARTH.ppm            checks table layout only (no GPU needed)
 //   layer_demo MOON.ppm EARTH.ppm W H SPP OUT.rgba       renders Layer::scene on device 0, writes raw RGBA8
+//   layer_demo --pt MOON.ppm EARTH.ppm W H NUM MAX OUT   path-traced main.rs scene: MAX/NUM progressive frames of
+//                                                        NUM spp (Raytracer::render_frame), writes the final RGBA8
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +17,30 @@ using namespace mirt_host;
 int main(int argc, char** argv)
 {
     try {
+        if (argc > 1 && std::strcmp(argv[1], "--pt") == 0) {
+            if (argc < 9) { std::fprintf(stderr, "usage: layer_demo --pt MOON.ppm EARTH.ppm W H NUM MAX OUT\n"); return 2; }
+            RenderParams rp;
+            rp.camera = default_fly_camera();
+            rp.viewport_w = (uint32_t)std::atoi(argv[4]); rp.viewport_h = (uint32_t)std::atoi(argv[5]);
+            rp.sampling.num_samples_per_pixel = (uint32_t)std::atoi(argv[6]);
+            rp.sampling.max_samples_per_pixel = (uint32_t)std::atoi(argv[7]);
+            Scene sc = Layer::scene(argv[2], argv[3]);
+            // src/main.rs:538-544: the wgpu path's sphere list (same materials, different spheres)
+            sc.spheres = { sphere_new({ 0.0f, -500.0f, -1.0f }, 500.0f, 0), sphere_new({ 0.0f, 1.0f, 0.0f }, 1.0f, 3),
+                           sphere_new({ -5.0f, 1.0f, 0.0f }, 1.0f, 2),     sphere_new({ 5.0f, 0.8f, 1.5f }, 0.8f, 1),
+                           sphere_new({ 5.0f, 1.2f, -1.5f }, 1.2f, 4) };
+            Raytracer rt(sc, rp);
+            std::vector<uint8_t> img;
+            int frames = 0;
+            while (rt.progress() < 1.0f) { img = rt.render_frame(); ++frames; }
+            img = rt.render_frame();                                    // one more: must change nothing
+            FILE* f = std::fopen(argv[8], "wb");
+            if (!f) return 1;
+            std::fwrite(img.data(), 1, img.size(), f);
+            std::fclose(f);
+            std::printf("pt: %d frames, progress %.2f, %zu bytes\n", frames, rt.progress(), img.size());
+            return 0;
+        }
         const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
         const int a = host_only ? 2 : 1;
         if (argc < a + 2) { std::fprintf(stderr, "usage: layer_demo [--host-only] MOON.ppm EARTH.ppm [W H SPP OUT]\n"); return 2; }

@@ -253,4 +253,89 @@ private:
     std::vector<uint8_t> rgba_;
 };
 
+// Raytracer — the path-traced mode behind the names of src/raytracer/mod.rs:20-394 (wgpu plumbing
+// omitted).  render_frame() = RenderProgress::next_frame (mod.rs:626-670) + the shader's accumulation.
+class Raytracer {
+public:
+    Raytracer(const Scene& scene, const RenderParams& rp, int device = 0, const MirtSkyState* sky = nullptr)
+        : rp_(rp), spheres_(scene.spheres)
+    {
+        rp.validate();                                                     // mod.rs:44-47
+        for (const Material& m : scene.materials) {                        // mod.rs:160-183 (same (odd, even) swap)
+            if (auto* l = std::get_if<Lambertian>(&m)) material_data_.push_back(gpu_material::lambertian(l->albedo, texels_));
+            else if (auto* me = std::get_if<Metal>(&m)) material_data_.push_back(gpu_material::metal(me->albedo, me->fuzz, texels_));
+            else if (auto* d = std::get_if<Dielectric>(&m)) material_data_.push_back(gpu_material::dielectric(d->refraction_index));
+            else { const auto& c = std::get<Checkerboard>(m); material_data_.push_back(gpu_material::checkerboard(c.odd, c.even, texels_)); }
+        }
+        if (sky) { sky_ = *sky; have_sky_ = true; }
+        camera_ = gpu_camera_new(rp.camera, rp.viewport_w, rp.viewport_h);
+        check(mirt_ctx_create(device, &ctx_));
+        upload();
+    }
+    ~Raytracer() { if (ctx_) mirt_ctx_destroy(ctx_); }
+    Raytracer(const Raytracer&) = delete;
+    Raytracer& operator=(const Raytracer&) = delete;
+
+    void set_render_params(const RenderParams& rp)                         // mod.rs:353-388
+    {
+        rp.validate();
+        rp_ = rp;
+        camera_ = gpu_camera_new(rp.camera, rp.viewport_w, rp.viewport_h);
+        check(mirt_ctx_set_camera(ctx_, &camera_));
+        accumulated_ = -1;                                                 // render_progress.reset()
+    }
+
+    // all max_samples_per_pixel samples in one launch
+    std::vector<uint8_t> render(uint64_t seed = 0, uint32_t flags = 0)
+    {
+        MirtParams p = params(rp_.sampling.max_samples_per_pixel, seed, flags);
+        std::vector<uint8_t> out((size_t)p.width * p.height * 4);
+        check(mirt_ctx_render(ctx_, &p, out.data(), out.size()));
+        return out;
+    }
+
+    // one progressive frame: add num_samples_per_pixel until max_samples_per_pixel, return the estimate
+    std::vector<uint8_t> render_frame(uint64_t seed = 0, uint32_t flags = 0)
+    {
+        MirtParams p = params(rp_.sampling.num_samples_per_pixel, seed, flags);
+        if (accumulated_ < 0) { check(mirt_ctx_accum_reset(ctx_, &p)); accumulated_ = 0; }
+        if ((uint32_t)accumulated_ + p.spp <= rp_.sampling.max_samples_per_pixel) {
+            check(mirt_ctx_accum_add(ctx_, &p, nullptr));
+            accumulated_ += (int)p.spp;
+        }
+        std::vector<uint8_t> out((size_t)p.width * p.height * 4);
+        check(mirt_ctx_accum_resolve(ctx_, &p, out.data(), out.size()));
+        return out;
+    }
+    float progress() const { return (accumulated_ < 0 ? 0.0f : (float)accumulated_) / (float)rp_.sampling.max_samples_per_pixel; }   // mod.rs:390-393
+
+private:
+    MirtParams params(uint32_t spp, uint64_t seed, uint32_t flags) const
+    {
+        MirtParams p{};
+        p.width = rp_.viewport_w; p.height = rp_.viewport_h; p.spp = spp; p.num_bounces = rp_.sampling.num_bounces;
+        p.mode = MIRT_MODE_PT; p.flags = flags | (have_sky_ ? (uint32_t)MIRT_FLAG_SKY_HOSEK : 0u); p.seed = seed;
+        return p;
+    }
+    void upload()
+    {
+        MirtScene sc{};
+        sc.camera = &camera_;
+        sc.spheres = spheres_.data(); sc.n_spheres = (uint32_t)spheres_.size();
+        sc.materials = material_data_.data(); sc.n_materials = (uint32_t)material_data_.size();
+        sc.texels = texels_.data(); sc.n_texels = texels_.size() / 3;
+        sc.sky = have_sky_ ? &sky_ : nullptr;
+        check(mirt_ctx_set_scene(ctx_, &sc));
+    }
+    RenderParams rp_;
+    std::vector<MirtSphere> spheres_;
+    std::vector<MirtMaterial> material_data_;
+    std::vector<float> texels_;
+    MirtGpuCamera camera_{};
+    MirtSkyState sky_{};
+    bool have_sky_ = false;
+    MirtContext* ctx_ = nullptr;
+    int accumulated_ = -1;
+};
+
 }  // namespace mirt_host
