@@ -584,6 +584,14 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
+    a.n_full_units = a.n_units;
+    if (pool && p->spp >= 256u && npix >= 64u * mirt::kStripPixels * (uint64_t)c->cu_count) {
+        // pool kernel on a frame that keeps the chip busy: the last ~6 % of the pixels are dispensed in
+        // 4-pixel strips so that the 5120 waves finish within a quarter strip of each other
+        const uint64_t full_px = (npix - npix / 16) / mirt::kStripPixels * mirt::kStripPixels;
+        a.n_full_units = (uint32_t)(full_px / mirt::kStripPixels);
+        a.n_units = a.n_full_units + (uint32_t)((npix - full_px + mirt::kTailStripPixels - 1) / mirt::kTailStripPixels);
+    }
     // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
     // the counting build keeps the reference's flat scan so that its work counters stay comparable)
     const bool use_grid = pt && !pool && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID) &&

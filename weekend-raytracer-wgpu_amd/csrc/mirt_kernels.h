@@ -57,6 +57,7 @@ static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte c
 constexpr uint32_t kGridMinSpheres = 32;
 constexpr uint32_t kGridMaxCells   = 8192;
 
+constexpr uint32_t kTailStripPixels = 4;
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
@@ -90,7 +91,9 @@ struct RenderArgs {
     uint32_t width, height, spp, num_bounces, flags, seed_mix, sample_begin;
     uint32_t row_begin, tile_rows, n_parts, part;
     uint32_t out_rows;                     // rows this launch writes
-    uint32_t n_units;                      // work units: strips (strip kernels) or tiles (pool kernel)
+    uint32_t n_units;                      // work units (strips) the dispenser hands out
+    uint32_t n_full_units;                 // pool kernel: units [0, n_full_units) are kStripPixels wide, the rest
+                                           // kTailStripPixels wide (short strips at the end even out the waves' finish times)
     uint32_t lds_bytes;
 };
 

@@ -849,8 +849,11 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     for (;;) {
         const uint32_t strip = next_unit(A, lane);
         if (strip >= A.n_units) break;
-        const uint32_t base_pix = strip * kStripPixels;
-        const uint32_t strip_pixels = (npix - base_pix < kStripPixels) ? (npix - base_pix) : kStripPixels;
+        const bool full = strip < A.n_full_units;          // the last few percent of the frame go out in short strips
+        const uint32_t base_pix = full ? strip * kStripPixels
+                                       : A.n_full_units * kStripPixels + (strip - A.n_full_units) * kTailStripPixels;
+        const uint32_t want_pixels = full ? kStripPixels : kTailStripPixels;
+        const uint32_t strip_pixels = (npix - base_pix < want_pixels) ? (npix - base_pix) : want_pixels;
         const uint32_t total_items = strip_pixels * A.spp;
         // scalar (per-strip) pixel addressing: one division here instead of two per work item
         const uint32_t base_ci = base_pix / A.width;
