@@ -701,7 +701,6 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t npix = A.out_rows * A.width;
-    const CamRegs C = load_camera(S, A);
 
     Work<COUNT> work;
     work.clear();
@@ -724,7 +723,10 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
                 bool alive = s < A.spp;
                 Rng rng;
                 f3 ro, rd;
-                generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
+                {   // camera constants are re-read from LDS per batch instead of living in 21 VGPRs (6 waves per SIMD)
+                    const CamRegs C = load_camera(S, A);
+                    generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
+                }
                 f3 thr = mk(1, 1, 1);
                 f3 color = mk(0, 0, 0);
 
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
 {
     using Lay = WavePoolLayout<SLOTS>;
     constexpr uint32_t RING = Lay::kRing;
-    static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 16 == 0, "slot ids are 8 bit");
+    static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 8 == 0, "slot ids are 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
     const SceneLds S = stage_scene<true>(A, smem, HOSEK);
     const uint32_t tid = threadIdx.x;
@@ -840,7 +842,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     unsigned char* const L_ring = pool + Lay::kOffRing;
 
     const uint32_t npix = A.out_rows * A.width;
-    const CamRegs C = load_camera(S, A);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     Work<COUNT> work;
@@ -923,6 +924,9 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 uint32_t x = base_x + pix, y = row0;
                 if (wide) { if (x >= A.width) { x -= A.width; y = row1; } }
                 else { const uint32_t pi = base_pix + pix; const uint32_t ci = pi / A.width; x = pi - ci * A.width; y = abs_row(A, ci); }
+                // camera constants are (re)read from LDS here, 6 broadcast ds_read_b128 per GEN step, instead of
+                // living in 21 VGPRs across the whole kernel: the kernel then fits 6 waves per SIMD
+                const CamRegs C = load_camera(S, A);
                 generate_primary(A, C, x, y, A.sample_begin + sample, rng, ro, rd);
                 thr = mk(1, 1, 1);
                 bounce = 0;
@@ -1113,19 +1117,20 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
 
-// pool geometries {threads per block, slots per wave}; [0] is the default.  128 slots x 52 B keeps a
-// wave's pool under 8 KB, so that 20 waves (the VGPR limit) still fit a CU's 160 KB of LDS.
-// Measured on config 3: 64 slots -> 68 % lane use, 1.4x slower; 256 slots -> 8 waves
-// per CU, 1.7x slower; 96 slots at 6 waves per SIMD (80 VGPRs, spills) -> same speed.
-static const PoolConfig kPoolConfigs[] = { { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
+// pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel needs 79 VGPRs
+// (6 waves per SIMD = 24 per CU); 104 slots x 52 B + rings + accumulators = 6.4 KB per wave keeps all 24
+// resident in a CU's 160 KB of LDS.  Measured on config 3: 128 slots (5 waves/SIMD)
+// +2.5 % time; 64 slots -> 68 % lane use, 1.4x; 256 slots -> 8 waves per CU, 1.7x; 88 slots at 7
+// waves per SIMD (72 VGPRs, spills) +10 %.
+static const PoolConfig kPoolConfigs[] = { { 256, 104, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
 PoolConfig pool_config(uint32_t i)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 128) ? WavePoolLayout<128>::kBytes
-                                                                                                : WavePoolLayout<256>::kBytes;
+    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 104) ? WavePoolLayout<104>::kBytes
+                            : (c.slots == 128) ? WavePoolLayout<128>::kBytes : WavePoolLayout<256>::kBytes;
     c.lds_bytes = per_wave * (c.threads / 64);
     return c;
 }
@@ -1134,9 +1139,10 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     switch (cfg) {
-    case 1:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
-    case 2:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
-    default: return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
+    case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
+    case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
+    case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
+    default: return launch_pool_cfg<256, 104>(a, grid_blocks, count, hosek, stream);
     }
 }
 
