@@ -180,7 +180,7 @@ def main() -> int:
         total_samples = WIDTH * HEIGHT * SPP
         value = total_samples * args.steps / elapsed / 1e6
         flops = algorithmic_flops(work)
-        kernel_name = "render_pt_pool_kernel<256,104,false,false>"     # default schedule for spp >= 48 (mirt_api.hip)
+        kernel_name = "render_pt_pool_kernel<256,112,false,false>"     # default schedule for spp >= 48 (mirt_api.hip)
         if base.flags & m.MIRT_FLAG_KERNEL_STRIP:
             kernel_name = "render_pt_strip_kernel<false,false>"
         traffic = profiled_traffic(kernel_name) if world == 1 else None

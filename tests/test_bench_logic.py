@@ -17,7 +17,7 @@ def test_algorithmic_flops_formula():
 
 
 def test_profiled_traffic_lookup_matches_committed_summaries():
-    got = bench.profiled_traffic("render_pt_pool_kernel<256,104,false,false>")
+    got = bench.profiled_traffic("render_pt_pool_kernel<256,112,false,false>")
     assert got is not None
     traffic, name = got
     d = json.loads((ROOT / "profiles" / name).read_text())

@@ -801,8 +801,8 @@ constexpr uint32_t OP_LAMBERTIAN = 0, OP_METAL = 1, OP_DIELECTRIC = 2, OP_CHECKE
 // The strip kernel loses half its lanes to divergence: a wave's 64 samples start on the same
 // pixel (same material) but scatter to different materials or leave the scene, and the per-lane
 // material switch runs every routine present.  Here a wave instead keeps SLOTS paths in LDS:
-//   q0 = {ro.xyz, t}  q1 = {rd.xyz, best}  q2 = {thr.xyz, rng}   (48 B, ds_*_b128)
-//   flags = pixel | bounce << 8 | has_miss << 16
+//   q0 = {hit point (or nothing after a miss), sphere | pixel << 12 | bounce << 16 | has_miss << 24}
+//   q1 = {incoming direction rd, rng}   q2 = {throughput, -}                 (48 B, ds_*_b128)
 // and every slot id sits in exactly one of six ring queues — the routine ("op") its path waits
 // for.  Each step the wave pops up to 64 ids from its FULLEST queue, gathers those paths, runs
 // that one routine for all lanes, then the common tail (bounce limit, nearest hit,
@@ -818,8 +818,7 @@ struct WavePoolLayout {
     static constexpr uint32_t kRing     = ring_capacity(SLOTS);               // per-queue ring capacity (power of two >= SLOTS)
     static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
-    static constexpr uint32_t kOffFlags = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32
-    static constexpr uint32_t kOffRing  = kOffFlags + SLOTS * 4;              // [kNumOps][kRing] u8
+    static constexpr uint32_t kOffRing  = kOffAcc + kStripPixels * 3 * 8;     // [kNumOps][kRing] u8
     static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * kRing + 15) / 16) * 16;
 };
 
@@ -838,7 +837,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     unsigned char* pool = smem + scene_bytes + wave * Lay::kBytes;
     uint4* const L_state = reinterpret_cast<uint4*>(pool + Lay::kOffState);
     unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
-    uint32_t* const L_flags = reinterpret_cast<uint32_t*>(pool + Lay::kOffFlags);
     unsigned char* const L_ring = pool + Lay::kOffRing;
 
     const uint32_t npix = A.out_rows * A.width;
@@ -864,7 +862,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         const uint32_t row1 = (base_ci + 1 < A.out_rows) ? abs_row(A, base_ci + 1) : row0;
 
         // all slots start in the OP_GEN queue
-        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_flags[s] = 0u; }
+        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_state[s * 3].w = 0u; }
         if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
         uint32_t head[kNumOps], tail[kNumOps];             // wave-uniform (SGPRs)
 #pragma unroll
@@ -891,22 +889,21 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             const bool has = lane < my_n;
             const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + ((my_begin + lane) & (RING - 1u))] : 0u;
             const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
-            const uint32_t fl = L_flags[slot];
-            f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));
-            const float t_hit = from_bits(q0.w);
+            const uint32_t fl = q0.w;
+            f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
             f3 rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
-            const int best = has ? (int)q1.w : 0;
+            const int best = has ? (int)(fl & 0xfffu) : 0;
             f3 thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
             Rng rng;
-            rng.state = q2.w;
-            uint32_t pix = fl & 0xffu;
-            uint32_t bounce = (fl >> 8) & 0xffu;
+            rng.state = q1.w;
+            uint32_t pix = (fl >> 12) & 0xfu;
+            uint32_t bounce = (fl >> 16) & 0xffu;
             bool alive = has;
             if constexpr (COUNT) { if (lane == 0) work.add(kCntWaveIters); }
 
             if (my_k == OP_GEN) {
                 // finish the previous path of this slot ...
-                if (has && ((fl >> 16) & 1u)) {
+                if (has && ((fl >> 24) & 1u)) {
                     work.add(kCntSky);
                     const f3 c = sky_color<HOSEK>(S, rd);
                     atomicAdd(&L_acc[pix * 3 + 0], (unsigned long long)to_fixed(thr.x * c.x));
@@ -933,7 +930,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             } else {
                 // sphereIntersection wgsl:431-440, then ONE scatter routine for the whole wave
                 const PreparedSphere sp = S.spheres[best];
-                const f3 hp = fma3(t_hit, rd, ro);
+                const f3 hp = ro;                          // computed by the tail of the step that found the hit
                 const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
                 const PreparedMaterial* m = &S.pmats[has ? sp.material_idx : 0u];
                 f3 ndir = rd, att = mk(1, 1, 1);
@@ -973,10 +970,11 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 }
             }
             if (has) {
-                L_state[slot * 3 + 0] = make_uint4(bits(ro.x), bits(ro.y), bits(ro.z), bits(closest));
-                L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), (uint32_t)nb);
-                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), rng.state);
-                L_flags[slot] = pix | (bounce << 8) | (miss << 16);
+                const f3 hp = fma3(closest, rd, ro);       // rayPointAtParameter (wgsl:442-444); unused after a miss
+                const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24);
+                L_state[slot * 3 + 0] = make_uint4(bits(hp.x), bits(hp.y), bits(hp.z), packed);
+                L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
+                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), 0u);
             }
             // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
 #pragma unroll
@@ -1117,19 +1115,19 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
 
-// pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel needs 79 VGPRs
-// (6 waves per SIMD = 24 per CU); 104 slots x 52 B + rings + accumulators = 6.4 KB per wave keeps all 24
+// pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
+// (6 waves per SIMD = 24 per CU); 112 slots x 48 B + rings + accumulators = 6.4 KB per wave keeps all 24
 // resident in a CU's 160 KB of LDS.  Measured on config 3: 128 slots (5 waves/SIMD)
 // +2.5 % time; 64 slots -> 68 % lane use, 1.4x; 256 slots -> 8 waves per CU, 1.7x; 88 slots at 7
 // waves per SIMD (72 VGPRs, spills) +10 %.
-static const PoolConfig kPoolConfigs[] = { { 256, 104, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
+static const PoolConfig kPoolConfigs[] = { { 256, 112, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
 PoolConfig pool_config(uint32_t i)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 104) ? WavePoolLayout<104>::kBytes
+    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 112) ? WavePoolLayout<112>::kBytes
                             : (c.slots == 128) ? WavePoolLayout<128>::kBytes : WavePoolLayout<256>::kBytes;
     c.lds_bytes = per_wave * (c.threads / 64);
     return c;
@@ -1142,7 +1140,7 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
     case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
     case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
     case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
-    default: return launch_pool_cfg<256, 104>(a, grid_blocks, count, hosek, stream);
+    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
 }
 
