@@ -116,7 +116,9 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n)
         }
     }
     if (small.size() < mirt::kGridMinSpheres / 2 || big.size() > 64) return blob;
-    double cell = 4.0 * r_med;                                   // a small sphere then spans at most 3 cells per axis
+    double cell_factor = 4.0;                                    // cell = 4 median radii: a binned sphere spans at most 3 cells per axis
+    if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) cell_factor = v; }   // tuning knob
+    double cell = cell_factor * r_med;
     uint32_t dims[3];
     for (;;) {
         uint64_t total = 1;
@@ -594,11 +596,12 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     }
     // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
     // the counting build keeps the reference's flat scan so that its work counters stay comparable)
+    const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
     const bool use_grid = pt && !pool && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID) &&
-                          scene_lds + c->grid_bytes <= (size_t)c->lds_per_block;
+                          scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block;
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
-    a.lds_bytes = (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0) + a.grid_bytes);
+    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes) : (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
 
     uint32_t blocks;
     if (pool) {

@@ -116,5 +116,6 @@ hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64
 hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t stream);
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream);
 size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek);
+size_t     scene_lds_bytes_grid(uint32_t n_spheres, bool hosek);
 
 }  // namespace mirt

@@ -37,13 +37,13 @@ struct SceneLds {
 
 // Cooperative global -> LDS copy of the scene tables, 16 B per thread per step.
 // PT = false stages the reference-layout material table, PT = true the prepared one.
-template <bool PT>
+template <bool PT, bool MATS_IN_LDS = true>
 MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hosek)
 {
     constexpr uint32_t kMatQuads = PT ? sizeof(PreparedMaterial) / 16 : sizeof(MirtMaterial) / 16;
     const uint32_t n_cam = sizeof(MirtGpuCamera) / 16;
     const uint32_t n_sph = A.n_spheres * 2;
-    const uint32_t n_mat = A.n_mats * kMatQuads;
+    const uint32_t n_mat = MATS_IN_LDS ? A.n_mats * kMatQuads : 0u;
     const uint32_t n_sky = hosek ? sizeof(MirtSkyState) / 16 : 0;
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const uint4* src_cam = reinterpret_cast<const uint4*>(A.cam);
@@ -64,16 +64,16 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     S.cam = reinterpret_cast<const float*>(smem);
     S.spheres = reinterpret_cast<const PreparedSphere*>(smem + 16 * n_cam);
     S.mats = reinterpret_cast<const MirtMaterial*>(smem + 16 * (n_cam + n_sph));
-    S.pmats = reinterpret_cast<const PreparedMaterial*>(smem + 16 * (n_cam + n_sph));
+    S.pmats = MATS_IN_LDS ? reinterpret_cast<const PreparedMaterial*>(smem + 16 * (n_cam + n_sph)) : A.pmats;
     S.sky = hosek ? reinterpret_cast<const float*>(smem + 16 * (n_cam + n_sph + n_mat)) : nullptr;
     S.end = smem + 16 * total;
     return S;
 }
 
-MIRT_DEV size_t scene_lds_bytes_dev(uint32_t n_spheres, uint32_t n_mats, bool hosek)
+MIRT_DEV size_t scene_lds_bytes_dev(uint32_t n_spheres, uint32_t n_mats, bool hosek, bool mats_in_lds = true)
 {
-    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) + (size_t)n_mats * sizeof(PreparedMaterial) +
-           (hosek ? sizeof(MirtSkyState) : 0);
+    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) +
+           (mats_in_lds ? (size_t)n_mats * sizeof(PreparedMaterial) : 0) + (hosek ? sizeof(MirtSkyState) : 0);
 }
 
 // compact output row -> absolute image row (MirtParams contract, include/mirt.h)
@@ -686,10 +686,12 @@ template <bool COUNT, bool HOSEK, bool GRID>
 __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SceneLds S = stage_scene<true>(A, smem, HOSEK);
+    // many-sphere scenes (GRID build): the material table (one 48-byte read per hit) stays in global memory / L2
+    // so that LDS holds only what every sphere TEST reads, and more waves fit a CU
+    const SceneLds S = stage_scene<true, !GRID>(A, smem, HOSEK);
     GridLds G{};
     if constexpr (GRID) {                                  // stage the grid behind the scene tables
-        unsigned char* gdst = smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK);
+        unsigned char* gdst = smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, false);
         for (uint32_t i = threadIdx.x; i < A.grid_bytes / 16; i += blockDim.x)
             reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(A.grid)[i];
         __syncthreads();
@@ -1073,6 +1075,11 @@ size_t scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek)
 {
     return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) +
            (size_t)n_mats * (pt ? sizeof(PreparedMaterial) : sizeof(MirtMaterial)) + (hosek ? sizeof(MirtSkyState) : 0);
+}
+
+size_t scene_lds_bytes_grid(uint32_t n_spheres, bool hosek)      // GRID build: materials are not staged
+{
+    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) + (hosek ? sizeof(MirtSkyState) : 0);
 }
 
 
