@@ -473,7 +473,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if ((rc = ensure_capacity(&c->d_spheres, &c->cap_spheres, (size_t)s->n_spheres)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_mats, &c->cap_mats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_texels, &c->cap_texels, (size_t)s->n_texels * 3)) != MIRT_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());      // renders may be in flight on caller streams (mirt_ctx_render_device)
     HIP_TRY(hipMemcpy(c->d_cam, s->camera, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
     if (s->n_spheres) HIP_TRY(hipMemcpy(c->d_spheres, prep.data(), prep.size() * sizeof(mirt::PreparedSphere), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
@@ -501,7 +501,7 @@ int mirt_ctx_set_camera(MirtContext* c, const MirtGpuCamera* cam)
     if (!c || !cam) return fail(MIRT_ERR_NULL_POINTER, "ctx/camera is null");
     if (!c->have_scene) return fail(MIRT_ERR_NO_SCENE, "set_scene has not been called");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());      // renders may be in flight on caller streams (mirt_ctx_render_device)
     HIP_TRY(hipMemcpy(c->d_cam, cam, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
     return MIRT_OK;
 }
