@@ -79,7 +79,7 @@ def test_scene_errors_match_oracle(gpu_ctx, oracle):
 def test_scene_too_large_and_null_pointers(gpu_ctx):
     cam = simple_camera(8, 8)
     mats, tex = m.flatten_materials([m.Material.Dielectric(1.5)] * 3)
-    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 3000          # 96 KB > LDS budget
+    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 4000          # 128 KB > the 120 KB LDS budget
     assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
     lib = m.lib()
     assert lib.mirt_ctx_set_scene(gpu_ctx._h, None) == _abi.MIRT_ERR_NULL_POINTER
@@ -166,3 +166,27 @@ def test_fast_sqrt_rcp_are_correctly_rounded(gpu_ctx):
     """The kernels' 5-instruction sqrt and 3-instruction reciprocal must equal the IEEE results for
     EVERY binary32 bit pattern on this device — the bit-parity claim against the CPU rests on it."""
     assert gpu_ctx.selftest_math() == (0, 0)
+
+
+def test_large_scene_with_one_material_per_sphere(gpu_ctx, oracle):
+    """2000 spheres with 2000 materials (64 KB + 96 KB of tables): beyond what fits LDS with the materials,
+    so only the grid build (materials in global memory) can run it — and the counting/flat builds must refuse
+    cleanly or fall back, never fault."""
+    rng = np.random.default_rng(5)
+    T = m.Texture
+    mats, spheres = [], []
+    for i in range(2000):
+        mats.append(m.Material.Lambertian(T.new_from_color(rng.random(3))) if i % 3 else m.Material.Metal(T.new_from_color(rng.random(3)), 0.2))
+        c = rng.normal(size=3) * 6.0
+        c[1] = abs(c[1]) * 0.2 + 0.1
+        spheres.append(m.Sphere.new(c, float(rng.uniform(0.05, 0.2)), i).to_c())
+    gm, tex = m.flatten_materials(mats)
+    w, h = 64, 36
+    sd = m.SceneData(simple_camera(w, h, eye=(0, 2, 14), vfov=40, focus=14), spheres, gm, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, 4, mode=m.MIRT_MODE_PT, num_bounces=4)
+    assert_images_equal(gpu_ctx.render(p), oracle.render(sd, p), "2000 spheres / 2000 materials")
+    for bad in (m.make_params(w, h, 4, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_NO_GRID), m.make_params(w, h, 4, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_COUNT_WORK)):
+        with pytest.raises(m.MirtError) as e:
+            gpu_ctx.render(bad)
+        assert e.value.status_name == "MIRT_ERR_SCENE_TOO_LARGE"

@@ -206,7 +206,6 @@ struct MirtContext {
     uint64_t n_texels = 0;
     bool     have_sky = false;
     uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
-    bool     mats_ok_for_pt = false;      // validation results cached at set_scene
     int      pt_scene_status = MIRT_OK;
     int      parity_scene_status = MIRT_OK;
     MirtGpuCamera*        d_cam = nullptr;
@@ -217,6 +216,7 @@ struct MirtContext {
     unsigned char* d_grid = nullptr;        // uniform grid blob (many-sphere scenes), see build_grid
     size_t cap_grid = 0;
     uint32_t grid_bytes = 0;
+    bool     fits_flat = true;               // spheres + materials fit the LDS budget (flat kernels usable)
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;
     size_t cap_spheres = 0, cap_mats = 0, cap_texels = 0;
@@ -404,10 +404,17 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_spheres && !s->spheres) return fail(MIRT_ERR_NULL_POINTER, "spheres is null");
     if (s->n_materials && !s->materials) return fail(MIRT_ERR_NULL_POINTER, "materials is null");
     if (s->n_texels && !s->texels) return fail(MIRT_ERR_NULL_POINTER, "texels is null");
-    if (mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) > mirt::kMaxLdsBytes)
+    // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
+    // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
+    const bool fits_flat = mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
+    const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres);
+    const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
+                           mirt::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;
+    if (!fits_flat && !fits_grid)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
                     s->n_materials, mirt::kMaxLdsBytes);
     HIP_TRY(hipSetDevice(c->device));
+    c->fits_flat = fits_flat;
 
     // mode-specific validity is decided here once and reported by the render call that needs it
     c->pt_scene_status = MIRT_OK;
@@ -480,9 +487,8 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_pmats, pmats.data(), pmats.size() * sizeof(mirt::PreparedMaterial), hipMemcpyHostToDevice));
     if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
     {
-        const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres);
-        c->grid_bytes = (uint32_t)grid.size();
-        if (!grid.empty()) {
+        c->grid_bytes = fits_grid ? (uint32_t)grid.size() : 0u;
+        if (fits_grid) {
             if ((rc = ensure_capacity(&c->d_grid, &c->cap_grid, grid.size())) != MIRT_OK) return rc;
             HIP_TRY(hipMemcpy(c->d_grid, grid.data(), grid.size(), hipMemcpyHostToDevice));
         }
@@ -574,7 +580,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_waves_per_cu >= 16;
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
-    if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block) pool = false;
+    if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block || !c->fits_flat) pool = false;
 
     mirt::RenderArgs a{};
     a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
@@ -602,6 +608,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes) : (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
+    if (!use_grid && !c->fits_flat)
+        return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "
+                    "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
 
     uint32_t blocks;
     if (pool) {

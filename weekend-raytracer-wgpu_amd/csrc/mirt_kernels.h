@@ -35,7 +35,6 @@ struct PreparedMaterial {
     float    tex[2][4];
 };
 static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
-constexpr uint32_t kMatTex1Is1x1 = 1u, kMatTex2Is1x1 = 2u;
 
 // Uniform grid over the small spheres of a many-sphere scene (>= kGridMinSpheres): the nearest-hit scan
 // visits only the cells a ray crosses (3D-DDA) plus a short list of "big" spheres.  The grid is
@@ -61,7 +60,7 @@ constexpr uint32_t kTailStripPixels = 4;
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
-constexpr uint32_t kMaxLdsBytes   = 64 * 1024;  // scene budget in LDS
+constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 KB per CU); sphere ids are 12 bit in the pool kernel
 
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
 constexpr uint32_t kDefaultPoolConfig = 0;
