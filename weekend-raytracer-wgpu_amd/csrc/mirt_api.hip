@@ -592,13 +592,43 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
-    a.n_full_units = a.n_units;
-    if (pool && p->spp >= 256u && npix >= 64u * mirt::kStripPixels * (uint64_t)c->cu_count) {
-        // pool kernel on a frame that keeps the chip busy: the last ~6 % of the pixels are dispensed in
-        // 4-pixel strips so that the 5120 waves finish within a quarter strip of each other
-        const uint64_t full_px = (npix - npix / 16) / mirt::kStripPixels * mirt::kStripPixels;
-        a.n_full_units = (uint32_t)(full_px / mirt::kStripPixels);
-        a.n_units = a.n_full_units + (uint32_t)((npix - full_px + mirt::kTailStripPixels - 1) / mirt::kTailStripPixels);
+    for (uint32_t l = 0; l <= mirt::kStripLevels; ++l) { a.lvl_unit[l] = a.n_units; a.lvl_pix[l] = (uint32_t)npix; }
+    a.lvl_unit[0] = 0;
+    a.lvl_pix[0] = 0;
+    if (pool) {
+        // Guided self-scheduling for the pool kernel: 16-pixel strips while more than 4 strips per resident
+        // wave remain, then 8- and 4-pixel strips under the same rule, so that the waves finish within a
+        // fraction of a strip of each other.  Measured on config 3 (tools/part_timing.py, one rank's share of
+        // an N-way partition vs 1/N of the whole frame): fixed 16-pixel strips 95 / 83 / 67 % at N = 2 / 4 / 8,
+        // this schedule 99 / 95 / 90 %; strips narrower than 4 pixels lose more to pool fill/drain than they
+        // gain.  Narrow strips also need width x spp >= 512 work items to keep a wave's pool busy.
+        const char* strip_mode = std::getenv("MIRT_STRIP_MODE");   // experiment knob: "16" = fixed 16-pixel strips
+        const uint64_t waves = (uint64_t)c->cu_count * 24u;
+        uint32_t min_width = 4;
+        while (min_width < mirt::kStripPixels && (uint64_t)min_width * p->spp < 512u) min_width *= 2;
+        if (strip_mode && strip_mode[0] == '1') min_width = mirt::kStripPixels;
+        double keep_factor = 4.0;
+        if (const char* e = std::getenv("MIRT_GSS_MINW")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v <= 16) min_width = v; }
+        if (const char* e = std::getenv("MIRT_GSS_KEEP")) { const double v = std::atof(e); if (v > 0.0 && v < 64.0) keep_factor = v; }
+        uint64_t pix = 0, unit = 0;
+        for (uint32_t l = 0; l < mirt::kStripLevels; ++l) {
+            const uint32_t width = mirt::kStripPixels >> l;
+            a.lvl_unit[l] = (uint32_t)unit;
+            a.lvl_pix[l] = (uint32_t)pix;
+            uint64_t level_px;
+            if (width <= min_width) {
+                level_px = npix - pix;                               // last usable level takes the rest
+            } else {
+                const uint64_t keep = (uint64_t)(keep_factor * (double)(waves * width));   // pixels left for the narrower levels
+                const uint64_t left = npix - pix;
+                level_px = left > keep ? (left - keep) / width * width : 0;
+            }
+            pix += level_px;
+            unit += (level_px + width - 1) / width;
+        }
+        a.lvl_unit[mirt::kStripLevels] = (uint32_t)unit;
+        a.lvl_pix[mirt::kStripLevels] = (uint32_t)npix;
+        a.n_units = (uint32_t)unit;
     }
     // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
     // the counting build keeps the reference's flat scan so that its work counters stay comparable)

@@ -56,7 +56,7 @@ static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte c
 constexpr uint32_t kGridMinSpheres = 32;
 constexpr uint32_t kGridMaxCells   = 8192;
 
-constexpr uint32_t kTailStripPixels = 4;
+constexpr uint32_t kStripLevels   = 5;    // strip widths 16, 8, 4, 2, 1
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
@@ -91,8 +91,11 @@ struct RenderArgs {
     uint32_t row_begin, tile_rows, n_parts, part;
     uint32_t out_rows;                     // rows this launch writes
     uint32_t n_units;                      // work units (strips) the dispenser hands out
-    uint32_t n_full_units;                 // pool kernel: units [0, n_full_units) are kStripPixels wide, the rest
-                                           // kTailStripPixels wide (short strips at the end even out the waves' finish times)
+    // pool kernel, guided self-scheduling: level l = strips of (kStripPixels >> l) pixels; it starts at unit
+    // lvl_unit[l] / pixel lvl_pix[l] (entry kStripLevels = end).  Strips shrink 16 -> 1 pixels towards the end of
+    // the frame so that all waves finish within a fraction of a strip of each other.
+    uint32_t lvl_unit[6];
+    uint32_t lvl_pix[6];
     uint32_t lds_bytes;
 };
 

@@ -841,7 +841,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
     unsigned char* const L_ring = pool + Lay::kOffRing;
 
-    const uint32_t npix = A.out_rows * A.width;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     Work<COUNT> work;
@@ -850,11 +849,18 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     for (;;) {
         const uint32_t strip = next_unit(A, lane);
         if (strip >= A.n_units) break;
-        const bool full = strip < A.n_full_units;          // the last few percent of the frame go out in short strips
-        const uint32_t base_pix = full ? strip * kStripPixels
-                                       : A.n_full_units * kStripPixels + (strip - A.n_full_units) * kTailStripPixels;
-        const uint32_t want_pixels = full ? kStripPixels : kTailStripPixels;
-        const uint32_t strip_pixels = (npix - base_pix < want_pixels) ? (npix - base_pix) : want_pixels;
+        // which level does this unit belong to?  (wave-uniform scalar code, once per strip)
+        uint32_t lvl = 0;
+#pragma unroll
+        for (uint32_t l = 1; l < kStripLevels; ++l) lvl = (strip >= A.lvl_unit[l]) ? l : lvl;
+        uint32_t unit0 = A.lvl_unit[0], pix0 = A.lvl_pix[0], pix_end = A.lvl_pix[1];
+#pragma unroll
+        for (uint32_t l = 1; l < kStripLevels; ++l)
+            if (lvl == l) { unit0 = A.lvl_unit[l]; pix0 = A.lvl_pix[l]; pix_end = A.lvl_pix[l + 1]; }
+        const uint32_t width_log2 = 4u - lvl;              // 16, 8, 4, 2, 1 pixels
+        const uint32_t base_pix = pix0 + ((strip - unit0) << width_log2);
+        const uint32_t want_pixels = 1u << width_log2;
+        const uint32_t strip_pixels = (pix_end - base_pix < want_pixels) ? (pix_end - base_pix) : want_pixels;
         const uint32_t total_items = strip_pixels * A.spp;
         // scalar (per-strip) pixel addressing: one division here instead of two per work item
         const uint32_t base_ci = base_pix / A.width;
@@ -917,8 +923,8 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 next_item += my_n;
                 alive = has && item < total_items;
                 uint32_t sample;
-                if (strip_pixels == kStripPixels) { sample = item / kStripPixels; pix = item % kStripPixels; }   // shifts
-                else { sample = item / strip_pixels; pix = item - sample * strip_pixels; }
+                if (strip_pixels == want_pixels) { sample = item >> width_log2; pix = item & (want_pixels - 1u); }
+                else { sample = item / strip_pixels; pix = item - sample * strip_pixels; }      // ragged last strip
                 // pixel -> (x, y): the strip starts at (base_x, row0) and may wrap into following rows
                 uint32_t x = base_x + pix, y = row0;
                 if (wide) { if (x >= A.width) { x -= A.width; y = row1; } }
