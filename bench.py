@@ -142,6 +142,13 @@ def main() -> int:
         if world > 1:
             dist.barrier()
 
+    if world > 1:
+        # communicator set-up, not a step: RCCL opens its point-to-point channels on first use, so push one
+        # gather of the (still empty) buffers through before anything is timed
+        m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
+        torch.cuda.synchronize()
+        barrier()
+
     for _ in range(args.warmup):
         frame.step()
     torch.cuda.synchronize()
