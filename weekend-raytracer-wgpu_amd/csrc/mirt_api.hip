@@ -206,6 +206,7 @@ struct MirtContext {
     uint64_t n_texels = 0;
     bool     have_sky = false;
     uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
+    bool     rare_routines = false;       // some sphere selects the checkerboard or the missing-material routine
     int      pt_scene_status = MIRT_OK;
     int      parity_scene_status = MIRT_OK;
     MirtGpuCamera*        d_cam = nullptr;
@@ -432,6 +433,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
             if (mi < s->n_materials) { const uint32_t id = s->materials[mi].id; seen |= 1u << (id < 4u ? id : 4u); }
         }
         c->n_shading_routines = (uint32_t)__builtin_popcount(seen);
+        c->rare_routines = (seen & 0x18u) != 0;
     }
     c->parity_scene_status = MIRT_OK;
     if (s->n_spheres > 0) {   // layer.rs:345-349 reads material_data[2] on every primary hit
@@ -448,7 +450,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         o.inv_r = 1.0f / in.radius;
         o.radius = in.radius;
         o.material_idx = in.material_idx;
-        o._pad = 0;
+        o.op = (in.material_idx < s->n_materials && s->materials[in.material_idx].id < 4u) ? s->materials[in.material_idx].id : 4u;
     }
     // PreparedMaterial: GpuMaterial + 1/x + the texel of every 1x1 texture (see mirt_kernels.h)
     std::vector<mirt::PreparedMaterial> pmats(s->n_materials);
@@ -664,7 +666,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
-    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, stream));
+    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, c->rare_routines, stream));
     else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     c->ev_used = ev + 1;
@@ -730,9 +732,13 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.roots = h[mirt::kCntRoots];
         c->stats.hits = h[mirt::kCntHits];
         for (int i = 0; i < 5; ++i) c->stats.scatter[i] = h[mirt::kCntScatter0 + i];
+
         c->stats.sky_misses = h[mirt::kCntSky];
         c->stats.lane_iterations = h[mirt::kCntLaneIters];
         c->stats.wave_iterations = h[mirt::kCntWaveIters];
+#ifdef MIRT_STAMP
+        c->stats.scatter[0] = h[12]; c->stats.scatter[1] = h[13]; c->stats.scatter[2] = h[14]; c->stats.sky_misses = h[15];
+#endif
         c->stats_counted = false;
     }
     *out = c->stats;

@@ -44,9 +44,26 @@ MIRT_DEV float sqrt_(float x)
     const float d = __builtin_fmaf(-g, g, x);
     float s = __builtin_fmaf(d, h, g);
     const bool odd = !(x >= 0x1p-100f && x <= 0x1p100f);
-    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {        // wave-uniform and rare
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {        // wave-uniform and rare
         asm volatile("; sqrt_: IEEE expansion" ::);           // keeps this a real branch (hipcc would otherwise
         s = odd ? sqrt_ieee(x) : s;                           // if-convert it and run BOTH sequences on every lane)
+    }
+    return s;
+}
+
+// sqrt_ for callers that only use the result on lanes where `want` holds (and x > 0 there): the other
+// lanes may carry negative or NaN arguments without sending the wave down the IEEE expansion.
+MIRT_DEV float sqrt_where(float x, bool want)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    float s = __builtin_fmaf(d, h, g);
+    const bool odd = want && !(x >= 0x1p-100f && x <= 0x1p100f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
+        asm volatile("; sqrt_where: IEEE expansion" ::);
+        s = odd ? sqrt_ieee(x) : s;
     }
     return s;
 }
@@ -58,7 +75,7 @@ MIRT_DEV float rcp_(float x)           // == 1.0f / x bit for bit
     float y = __builtin_fmaf(y0, e, y0);
     const float ax = __builtin_fabsf(x);
     const bool odd = !(ax >= 0x1p-100f && ax <= 0x1p100f);
-    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
         asm volatile("; rcp_: IEEE expansion" ::);
         y = odd ? rcp_ieee(x) : y;
     }

@@ -18,7 +18,7 @@ struct PreparedSphere {
     float    cx, cy, cz, rr;
     float    inv_r, radius;
     uint32_t material_idx;
-    uint32_t _pad;
+    uint32_t op;            // shading routine of its material: min(GpuMaterial.id, 4) (4 = missing material, wgsl:309)
 };
 static_assert(sizeof(PreparedSphere) == 32, "PreparedSphere must stay 2 x 16 B for ds_read_b128");
 
@@ -112,7 +112,7 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i);
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, bool rare_ops, hipStream_t stream);
 hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
                           uint32_t flags, hipStream_t stream);
 hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t stream);

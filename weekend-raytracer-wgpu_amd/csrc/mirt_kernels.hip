@@ -347,7 +347,33 @@ MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x
     rd = fma3(v, C.ver, fma3(u, C.hor, C.llc)) - ro;
 }
 
-// nearest hit (wgsl:135-145, 407-429): every lane walks the same sphere list in LDS
+// nearest hit (wgsl:135-145, 407-429): every lane walks the same sphere list in LDS.
+// One sphere: straight-line code, no divergent branch — lanes without a real root are masked out of the
+// two comparisons instead (their sqrt argument is negative or NaN and never used).
+template <bool COUNT>
+MIRT_DEV void hit_sphere(const float4 s4, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best,
+                         Work<COUNT>& work)
+{
+    const f3 oc = ro - mk(s4.x, s4.y, s4.z);
+    const float b = dot(oc, rd);
+    const float cq = dot(oc, oc) - s4.w;
+    const float disc = fma_(b, b, -(a * cq));
+    if (alive && disc > 0.0f) {                              // skipped when no lane of the wave can hit
+        const float sq = sqrt_(disc);
+        const float t0 = (-b - sq) * inv_a;
+        const float t1 = (-b + sq) * inv_a;
+        const bool ok0 = (t0 < closest) && (t0 > kMinT);    // first root, else second (wgsl:415-425), branch-free
+        const bool ok1 = (t1 < closest) && (t1 > kMinT);
+#ifndef MIRT_STAMP
+        work.add(kCntRoots, ok0 ? 1u : 2u);
+#endif
+        const float t = ok0 ? t0 : t1;
+        const bool ok = ok0 || ok1;
+        closest = ok ? t : closest;
+        best = ok ? (int)i : best;
+    }
+}
+
 template <bool COUNT>
 MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bool alive, float& closest_out,
                          Work<COUNT>& work)
@@ -357,25 +383,15 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
     float closest = kMaxT;
     int best = -1;
     if (alive) { work.add(kCntRays); work.add(kCntTests, n_spheres); }
-    for (uint32_t i = 0; i < n_spheres; ++i) {
-        const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
-        const f3 oc = ro - mk(s4.x, s4.y, s4.z);
-        const float b = dot(oc, rd);
-        const float cq = dot(oc, oc) - s4.w;
-        const float disc = fma_(b, b, -(a * cq));
-        if (alive && disc > 0.0f) {                              // skipped when no lane of the wave can hit
-            const float sq = sqrt_(disc);
-            const float t0 = (-b - sq) * inv_a;
-            const float t1 = (-b + sq) * inv_a;
-            const bool ok0 = (t0 < closest) && (t0 > kMinT);    // first root, else second (wgsl:415-425), branch-free
-            const bool ok1 = (t1 < closest) && (t1 > kMinT);
-            work.add(kCntRoots, ok0 ? 1u : 2u);
-            const float t = ok0 ? t0 : t1;
-            const bool ok = ok0 || ok1;
-            closest = ok ? t : closest;
-            best = ok ? (int)i : best;
-        }
+    const float4* sph = reinterpret_cast<const float4*>(S.spheres);     // {centre, radius^2} is the first half of a PreparedSphere
+    uint32_t i = 0;
+    for (; i + 3 <= n_spheres; i += 3) {                                 // three LDS reads in flight per round trip
+        const float4 s0 = sph[2 * i], s1 = sph[2 * i + 2], s2 = sph[2 * i + 4];
+        hit_sphere<COUNT>(s0, i, ro, rd, a, inv_a, alive, closest, best, work);
+        hit_sphere<COUNT>(s1, i + 1, ro, rd, a, inv_a, alive, closest, best, work);
+        hit_sphere<COUNT>(s2, i + 2, ro, rd, a, inv_a, alive, closest, best, work);
     }
+    for (; i < n_spheres; ++i) hit_sphere<COUNT>(sph[2 * i], i, ro, rd, a, inv_a, alive, closest, best, work);
     closest_out = closest;
     return best;
 }
@@ -587,14 +603,17 @@ MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng
     const float ratio = inside ? m->x : m->inv_x;
     const float dt = dot(uvn, outn);
     const float disc = fma_(-(ratio * ratio), fma_(-dt, dt, 1.0f), 1.0f);
-    if (disc > 0.0f) {
-        const float sq = sqrt_(disc);
-        const f3 q = fma3(-dt, outn, uvn);
-        ndir = normalize(fma3(-sq, outn, ratio * q));
-        (void)rng.next();
-    } else {
-        ndir = reflect3(rd, hn);
-    }
+    // both outcomes in straight-line code and a select (no divergent if/else): total internal reflection
+    // keeps the reflected direction and does NOT consume the Schlick draw
+    const bool refracts = disc > 0.0f;
+    const float sq = refracts ? sqrt_where(disc, refracts) : 0.0f;     // 0 keeps the unused lanes finite
+    const f3 q = fma3(-dt, outn, uvn);
+    const f3 refr = normalize(fma3(-sq, outn, ratio * q));
+    const f3 refl = reflect3(rd, hn);
+    Rng drawn = rng;
+    (void)drawn.next();
+    rng.state = refracts ? drawn.state : rng.state;
+    ndir = mk(refracts ? refr.x : refl.x, refracts ? refr.y : refl.y, refracts ? refr.z : refl.z);
     att = mk(1, 1, 1);
 }
 
@@ -824,7 +843,11 @@ struct WavePoolLayout {
     static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * kRing + 15) / 16) * 16;
 };
 
-template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK>
+// RARE = false: the host has checked that no sphere selects the checkerboard or the missing-material
+// routine, so their two queues are compiled out of the pick / pop / push loops.
+template <bool RARE> constexpr bool op_in_build(uint32_t k) { return RARE || (k != OP_CHECKER && k != OP_MISSING); }
+
+template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, bool RARE = true>
 __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
 {
     using Lay = WavePoolLayout<SLOTS>;
@@ -878,10 +901,15 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         uint32_t next_item = 0;
 
         for (;;) {
+#ifdef MIRT_STAMP
+            unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+            if constexpr (COUNT) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory"); }
+#endif
             // ---- pick the fullest queue ----
             uint32_t my_k = OP_NONE, my_n = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
+                if (!op_in_build<RARE>(k)) continue;
                 const uint32_t c = tail[k] - head[k];
                 if (c > my_n) { my_n = c; my_k = k; }
             }
@@ -890,13 +918,17 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             uint32_t my_begin = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
+                if (!op_in_build<RARE>(k)) continue;
                 if (my_k == k) { my_begin = head[k]; head[k] += my_n; }
             }
 
             // ---- pop + gather ----
             const bool has = lane < my_n;
             const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + ((my_begin + lane) & (RING - 1u))] : 0u;
-            const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
+            uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
+#ifdef MIRT_STAMP
+            if constexpr (COUNT) { asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st1) :: "memory"); asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); }
+#endif
             const uint32_t fl = q0.w;
             f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
             f3 rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
@@ -942,14 +974,23 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
                 const PreparedMaterial* m = &S.pmats[has ? sp.material_idx : 0u];
                 f3 ndir = rd, att = mk(1, 1, 1);
-                if (has) {
-                    switch (my_k) {                        // wave-uniform
-                    case OP_LAMBERTIAN: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
-                    case OP_METAL:      work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
-                    case OP_DIELECTRIC: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
-                    case OP_CHECKER:    work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
-                    default:            work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
-                    }
+                // lanes without a slot run the routine too, on slot 0's (valid) state: their results are never
+                // stored, and leaving them in saves an exec-mask region around every routine
+                if (my_k == OP_LAMBERTIAN) {               // wave-uniform dispatch
+                    if (has) work.add(kCntScatter0);
+                    shade_lambertian(A, m, hn, rng, ndir, att);
+                } else if (my_k == OP_METAL) {
+                    if (has) work.add(kCntScatter1);
+                    shade_metal(A, m, rd, hn, rng, ndir, att);
+                } else if (!RARE || my_k == OP_DIELECTRIC) {
+                    if (has) work.add(kCntScatter2);
+                    shade_dielectric(m, rd, hn, rng, ndir, att);
+                } else if (my_k == OP_CHECKER) {
+                    if (has) work.add(kCntScatter3);
+                    shade_checkerboard(A, m, hp, hn, rng, ndir, att);
+                } else {
+                    if (has) work.add(kCntScatter4);
+                    shade_missing(hn, rng, ndir, att);
                 }
                 ro = hp;
                 rd = ndir;
@@ -957,6 +998,9 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 bounce += 1;
             }
 
+#ifdef MIRT_STAMP
+            if constexpr (COUNT) { asm volatile("" : "+v"(rd.x), "+v"(ro.x), "+v"(thr.x), "+v"(rng.state)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st2) :: "memory"); asm volatile("" : "+v"(rd.x), "+v"(ro.x), "+v"(thr.x), "+v"(rng.state)); }
+#endif
             // common tail: bounce limit (wgsl:130), nearest hit, classification
             uint32_t new_op = OP_NONE;
             uint32_t miss = 0;
@@ -964,19 +1008,12 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
             float closest;
             const int nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
-            if (alive) {
-                new_op = OP_GEN;                           // path ended (bounce limit: contributes nothing)
-                if (trace) {
-                    if (nb >= 0) {
-                        work.add(kCntHits);
-                        const uint32_t id = S.pmats[S.spheres[nb].material_idx].id;
-                        new_op = (id < 4u) ? ((id == 0u) ? OP_LAMBERTIAN : (id == 1u) ? OP_METAL : (id == 2u) ? OP_DIELECTRIC : OP_CHECKER)
-                                           : OP_MISSING;
-                    } else {
-                        miss = 1;                          // left the scene: OP_GEN adds throughput x sky
-                    }
-                }
-            }
+            const bool hit = trace && nb >= 0;
+            if (hit) work.add(kCntHits);
+            miss = (trace && nb < 0) ? 1u : 0u;            // left the scene: OP_GEN adds throughput x sky
+#ifdef MIRT_STAMP
+            if constexpr (COUNT) { asm volatile("" : "+v"(new_op), "+v"(closest)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st3) :: "memory"); asm volatile("" : "+v"(new_op), "+v"(closest)); }
+#endif
             if (has) {
                 const f3 hp = fma3(closest, rd, ro);       // rayPointAtParameter (wgsl:442-444); unused after a miss
                 const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24);
@@ -984,13 +1021,25 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
                 L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), 0u);
             }
+            // next routine, branch-free (after the state is stored: fewer live registers): the op codes ARE
+            // min(material id, 4) and are kept with the sphere.  OP_GEN also when the bounce limit ended the path.
+            static_assert(OP_LAMBERTIAN == 0 && OP_METAL == 1 && OP_DIELECTRIC == 2 && OP_CHECKER == 3 && OP_MISSING == 4, "op = min(id, 4)");
+            new_op = alive ? (hit ? S.spheres[hit ? nb : 0].op : OP_GEN) : OP_NONE;
             // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
+                if (!op_in_build<RARE>(k)) continue;
                 const unsigned long long mk_ = __ballot(new_op == k);
                 if (new_op == k) L_ring[k * RING + ((tail[k] + (uint32_t)__popcll(mk_ & lt_mask)) & (RING - 1u))] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
             }
+#ifdef MIRT_STAMP
+            if constexpr (COUNT) {
+                unsigned long long st4; asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st4) :: "memory");
+                if (lane == 0) { work.add(12, (uint32_t)(st1 - st0)); work.add(my_k == OP_GEN ? 13 : 14, (uint32_t)(st2 - st1)); work.add(15, (uint32_t)(st3 - st2));
+                                 work.add(kCntScatter4, (uint32_t)(st4 - st3)); work.add(my_k == OP_GEN ? kCntScatter3 : kCntRoots, 1); }
+            }
+#endif
         }
 
         // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
@@ -1119,11 +1168,13 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
 }
 
 template <uint32_t T, uint32_t SL, uint32_t MW = 1>
-static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, hipStream_t stream)
+static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, bool rare, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(T);
     if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, false>, g, b, a, stream);
+    if (!rare) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, false>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, false>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true>, g, b, a, stream)
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
@@ -1146,14 +1197,14 @@ PoolConfig pool_config(uint32_t i)
     return c;
 }
 
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, hipStream_t stream)
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, bool rare_ops, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     switch (cfg) {
-    case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, stream);
-    case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, stream);
-    case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, stream);
-    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, stream);   // 6 waves per SIMD: <= 80 VGPRs
+    case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, rare_ops, stream);
+    case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, rare_ops, stream);
+    case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, rare_ops, stream);
+    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, rare_ops, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
 }
 
