@@ -649,6 +649,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
         const uint32_t by_waves = 24u / (pc.threads / 64u);   // 79 VGPRs -> 6 waves per SIMD   // upper bound; the hardware admits what VGPRs/LDS allow
         if (per_cu > by_waves) per_cu = by_waves;
+        if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // tuning knob: fewer resident waves
         if (per_cu == 0u) per_cu = 1u;
         blocks = (uint32_t)c->cu_count * per_cu;
         const uint32_t units_per_block = pc.threads / 64u;

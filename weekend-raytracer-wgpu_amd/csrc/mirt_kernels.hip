@@ -536,21 +536,25 @@ MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n)
 {
     const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[k][0]);    // one ds_read_b128 (m lives in LDS)
-    const float t[4] = { t4.x, t4.y, t4.z, t4.w };
     const bool one = (m->flags >> k) & 1u;
-    if (one) {
-        const bool safe_v = n.y > -0.999999f;
-        const bool safe_u = (n.x >= 0.0f) || (abs_(n.z) > 1.0e-5f * abs_(n.x));
-        if (safe_u && safe_v) return mk(t[0], t[1], t[2]);
+    // plain mask logic (no short-circuit) so that the shortcut is straight-line code; the full lookup sits
+    // behind ONE wave-uniform, rarely taken branch
+    const bool fast = one & (n.y > -0.999999f) & ((n.x >= 0.0f) | (abs_(n.z) > 1.0e-5f * abs_(n.x)));
+    f3 c = mk(t4.x, t4.y, t4.z);
+    if (__builtin_expect(__ballot(!fast) != 0ull, 0)) {
+        asm volatile("; albedo_at: full texture lookup" ::);
+        if (!fast) {
+            const float theta = acos_(-n.y);
+            const float phi = atan2_(-n.z, n.x) + kPi;
+            const float u = (0.5f * kFrac1Pi) * phi;
+            const float v = kFrac1Pi * theta;
+            const uint32_t w = one ? 1u : bits(t4.x);
+            const uint32_t h = one ? 1u : bits(t4.y);
+            const uint32_t off = one ? bits(t4.w) : bits(t4.z);
+            c = texture_lookup(A, w, h, off, u, v);
+        }
     }
-    const float theta = acos_(-n.y);
-    const float phi = atan2_(-n.z, n.x) + kPi;
-    const float u = (0.5f * kFrac1Pi) * phi;
-    const float v = kFrac1Pi * theta;
-    const uint32_t w = one ? 1u : bits(t[0]);
-    const uint32_t h = one ? 1u : bits(t[1]);
-    const uint32_t off = one ? bits(t[3]) : bits(t[2]);
-    return texture_lookup(A, w, h, off, u, v);
+    return c;
 }
 
 // scatterLambertian (wgsl:204-242): cosine-weighted direction around n through the Pixar ONB
@@ -574,7 +578,11 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
     // max() pick their second argument and the quotient is x/x = 1 exactly; only grazing directions divide.
     const float dnc = dn * kFrac1Pi;
     float kk = 1.0f;
-    if (!(dnc > kEpsilon)) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
+    const bool grazing = !(dnc > kEpsilon);
+    if (__builtin_expect(__ballot(grazing) != 0ull, 0)) {
+        asm volatile("; scatter_lambertian: grazing direction" ::);
+        if (grazing) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
+    }
     atten = kk * albedo_at(A, m, k, n);
     dir = wi;
 }
@@ -895,9 +903,11 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         // all slots start in the OP_GEN queue
         for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_state[s * 3].w = 0u; }
         if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
-        uint32_t head[kNumOps], tail[kNumOps];             // wave-uniform (SGPRs)
+        // Each queue is a STACK of slot ids (order of service is free: the image does not depend on it), so a
+        // queue is described by its depth alone -- six SGPRs, no heads, no index wrap.
+        uint32_t tail[kNumOps];                            // wave-uniform (SGPRs)
 #pragma unroll
-        for (uint32_t k = 0; k < kNumOps; ++k) { head[k] = 0; tail[k] = (k == OP_GEN) ? SLOTS : 0u; }
+        for (uint32_t k = 0; k < kNumOps; ++k) tail[k] = (k == OP_GEN) ? SLOTS : 0u;
         uint32_t next_item = 0;
 
         for (;;) {
@@ -905,26 +915,28 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
             if constexpr (COUNT) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory"); }
 #endif
-            // ---- pick the fullest queue ----
-            uint32_t my_k = OP_NONE, my_n = 0;
+            // ---- pick the deepest queue: max over keys depth << 3 | (7 - op); ties go to the lower op ----
+            uint32_t key = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
                 if (!op_in_build<RARE>(k)) continue;
-                const uint32_t c = tail[k] - head[k];
-                if (c > my_n) { my_n = c; my_k = k; }
+                const uint32_t kk = (tail[k] << 3) | (7u - k);
+                key = (kk > key) ? kk : key;
             }
-            if (my_n == 0) break;                          // every queue empty: strip finished
-            my_n = (my_n > 64u) ? 64u : my_n;
-            uint32_t my_begin = 0;
+            const uint32_t depth = key >> 3;
+            if (depth == 0) break;                         // every queue empty: strip finished
+            const uint32_t my_k = 7u - (key & 7u);
+            const uint32_t my_n = (depth > 64u) ? 64u : depth;
+            const uint32_t my_begin = depth - my_n;        // the top my_n entries
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
                 if (!op_in_build<RARE>(k)) continue;
-                if (my_k == k) { my_begin = head[k]; head[k] += my_n; }
+                tail[k] -= (my_k == k) ? my_n : 0u;
             }
 
             // ---- pop + gather ----
             const bool has = lane < my_n;
-            const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + ((my_begin + lane) & (RING - 1u))] : 0u;
+            const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + my_begin + lane] : 0u;
             uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
 #ifdef MIRT_STAMP
             if constexpr (COUNT) { asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st1) :: "memory"); asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); }
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             for (uint32_t k = 0; k < kNumOps; ++k) {
                 if (!op_in_build<RARE>(k)) continue;
                 const unsigned long long mk_ = __ballot(new_op == k);
-                if (new_op == k) L_ring[k * RING + ((tail[k] + (uint32_t)__popcll(mk_ & lt_mask)) & (RING - 1u))] = (unsigned char)slot;
+                if (new_op == k) L_ring[k * RING + tail[k] + (uint32_t)__popcll(mk_ & lt_mask)] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
             }
 #ifdef MIRT_STAMP
