@@ -18,7 +18,7 @@ scene = sys.argv[3] if len(sys.argv) > 3 else "three_spheres"
 w, h = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1920, 1080)
 ctx = m.Context(0)
 ctx.set_scene(scene_data(scene, w, h))
-variants = [("strip", m.MIRT_FLAG_KERNEL_STRIP, None)] + [(f"pool{c}", m.MIRT_FLAG_KERNEL_POOL, c) for c in (0, 1)]
+variants = [("strip", m.MIRT_FLAG_KERNEL_STRIP, None)] + [(f"pool{c}", m.MIRT_FLAG_KERNEL_POOL, c) for c in (0, 4)]
 times = {n: [] for n, _, _ in variants}
 ref = None
 for r in range(rounds + 1):

@@ -206,7 +206,7 @@ struct MirtContext {
     uint64_t n_texels = 0;
     bool     have_sky = false;
     uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
-    bool     rare_routines = false;       // some sphere selects the checkerboard or the missing-material routine
+    uint32_t queue_routine[5] = {0, 1, 2, 3, 4};   // dense numbering of the routines present (pool kernel queues)
     int      pt_scene_status = MIRT_OK;
     int      parity_scene_status = MIRT_OK;
     MirtGpuCamera*        d_cam = nullptr;
@@ -426,14 +426,18 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         if ((m.id == 0 || m.id == 1 || m.id == 3) && !desc_ok(m.desc1, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
         if (m.id == 3 && !desc_ok(m.desc2, s->n_texels)) c->pt_scene_status = MIRT_ERR_TEXEL_RANGE;
     }
-    {   // how many different scatter routines can a path meet?  (decides the path-traced schedule)
+    uint32_t routine_queue[5] = {0, 1, 2, 3, 4};    // routine id -> queue of the pool kernel
+    {   // which scatter routines can a path meet?  (decides the path-traced schedule; the pool kernel
+        // numbers the routines present densely so that scenes with <= 3 of them run a 4-queue build)
         uint32_t seen = 0;
         for (uint32_t i = 0; i < s->n_spheres; ++i) {
             const uint32_t mi = s->spheres[i].material_idx;
             if (mi < s->n_materials) { const uint32_t id = s->materials[mi].id; seen |= 1u << (id < 4u ? id : 4u); }
         }
         c->n_shading_routines = (uint32_t)__builtin_popcount(seen);
-        c->rare_routines = (seen & 0x18u) != 0;
+        uint32_t q = 0;
+        for (uint32_t r = 0; r < 5; ++r) if (seen & (1u << r)) { routine_queue[r] = q; c->queue_routine[q] = r; ++q; }
+        for (uint32_t r = 0; r < 5; ++r) if (!(seen & (1u << r))) { routine_queue[r] = q; c->queue_routine[q] = r; ++q; }
     }
     c->parity_scene_status = MIRT_OK;
     if (s->n_spheres > 0) {   // layer.rs:345-349 reads material_data[2] on every primary hit
@@ -450,7 +454,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         o.inv_r = 1.0f / in.radius;
         o.radius = in.radius;
         o.material_idx = in.material_idx;
-        o.op = (in.material_idx < s->n_materials && s->materials[in.material_idx].id < 4u) ? s->materials[in.material_idx].id : 4u;
+        o.op = routine_queue[(in.material_idx < s->n_materials && s->materials[in.material_idx].id < 4u) ? s->materials[in.material_idx].id : 4u];
     }
     // PreparedMaterial: GpuMaterial + 1/x + the texel of every 1x1 texture (see mirt_kernels.h)
     std::vector<mirt::PreparedMaterial> pmats(s->n_materials);
@@ -572,7 +576,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) pool_cfg = (uint32_t)v;
     }
-    const mirt::PoolConfig pc = mirt::pool_config(pool_cfg);
+    const uint32_t pool_nq = mirt::pool_scatter_queues(c->n_shading_routines, count);
+    const mirt::PoolConfig pc = mirt::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when paths diverge over >= 2 scatter routines,
     // a strip holds enough samples to keep the pool full, and the pools still leave >= 16 waves
     // per CU resident beside the scene tables (measured: 1 sphere 0.9x, 3 spheres 1.4x, 5 spheres
@@ -593,6 +598,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.sample_begin = p->sample_begin;
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
+    for (int q = 0; q < 5; ++q) a.queue_routine[q] = c->queue_routine[q];
     a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
     for (uint32_t l = 0; l <= mirt::kStripLevels; ++l) { a.lvl_unit[l] = a.n_units; a.lvl_pix[l] = (uint32_t)npix; }
     a.lvl_unit[0] = 0;
@@ -605,7 +611,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // this schedule 99 / 95 / 90 %; strips narrower than 4 pixels lose more to pool fill/drain than they
         // gain.  Narrow strips also need width x spp >= 512 work items to keep a wave's pool busy.
         const char* strip_mode = std::getenv("MIRT_STRIP_MODE");   // experiment knob: "16" = fixed 16-pixel strips
-        const uint64_t waves = (uint64_t)c->cu_count * 24u;
+        const uint64_t waves = (uint64_t)c->cu_count * (pool_waves_per_cu < 32u ? pool_waves_per_cu : 32u);   // resident waves (LDS-bound)
         uint32_t min_width = 4;
         while (min_width < mirt::kStripPixels && (uint64_t)min_width * p->spp < 512u) min_width *= 2;
         if (strip_mode && strip_mode[0] == '1') min_width = mirt::kStripPixels;
@@ -647,7 +653,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     uint32_t blocks;
     if (pool) {
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
-        const uint32_t by_waves = 24u / (pc.threads / 64u);   // 79 VGPRs -> 6 waves per SIMD   // upper bound; the hardware admits what VGPRs/LDS allow
+        const uint32_t by_waves = 32u / (pc.threads / 64u);   // upper bound; LDS decides (6 blocks of 4 waves with 112-slot pools)
         if (per_cu > by_waves) per_cu = by_waves;
         if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // tuning knob: fewer resident waves
         if (per_cu == 0u) per_cu = 1u;
@@ -667,7 +673,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
-    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, c->rare_routines, stream));
+    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
     else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     c->ev_used = ev + 1;

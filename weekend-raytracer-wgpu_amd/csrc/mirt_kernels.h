@@ -18,7 +18,7 @@ struct PreparedSphere {
     float    cx, cy, cz, rr;
     float    inv_r, radius;
     uint32_t material_idx;
-    uint32_t op;            // shading routine of its material: min(GpuMaterial.id, 4) (4 = missing material, wgsl:309)
+    uint32_t op;            // pool kernel: queue of its material's shading routine (RenderArgs.queue_routine)
 };
 static_assert(sizeof(PreparedSphere) == 32, "PreparedSphere must stay 2 x 16 B for ds_read_b128");
 
@@ -96,6 +96,7 @@ struct RenderArgs {
     // the frame so that all waves finish within a fraction of a strip of each other.
     uint32_t lvl_unit[6];
     uint32_t lvl_pix[6];
+    uint32_t queue_routine[5];             // pool kernel: scatter queue q runs routine queue_routine[q] = min(GpuMaterial.id, 4)
     uint32_t lds_bytes;
 };
 
@@ -111,8 +112,9 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t 
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, hipStream_t stream);
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
-PoolConfig pool_config(uint32_t i);
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, bool rare_ops, hipStream_t stream);
+PoolConfig pool_config(uint32_t i, uint32_t nq);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
+uint32_t pool_scatter_queues(uint32_t n_routines, bool count);
 hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
                           uint32_t flags, hipStream_t stream);
 hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t stream);

@@ -820,8 +820,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
 
 // shading routines ("ops") a path can wait for: the five scatter routines of scatterRay
 // (wgsl:174-314) and OP_GEN = finish the path (add throughput x sky) + start the next work item
-constexpr uint32_t OP_LAMBERTIAN = 0, OP_METAL = 1, OP_DIELECTRIC = 2, OP_CHECKER = 3, OP_MISSING = 4, OP_GEN = 5,
-                   OP_NONE = 6, kNumOps = 6;
+// Routine ids (= min(GpuMaterial.id, 4)).  A scene's routines are numbered densely on the host (queue q runs
+// routine RenderArgs.queue_routine[q], PreparedSphere.op holds q), so a kernel built for NQ scatter queues
+// has NQ + 1 queues: 0..NQ-1 scatter, NQ = OP_GEN.
+constexpr uint32_t RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2, RT_CHECKER = 3;
+constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 
 // ------------------------------------------------------------------------------------------
 // render_pt_pool — wave-private path pool: every wave-instruction runs ONE shading routine
@@ -840,25 +843,21 @@ constexpr uint32_t OP_LAMBERTIAN = 0, OP_METAL = 1, OP_DIELECTRIC = 2, OP_CHECKE
 // pixel), their 64-bit accumulators, the item counter and all queue heads/tails in SGPRs.
 // Nothing is shared between waves after the scene has been staged: no barrier, no inter-wave
 // atomic.  (A block-level pool with barriers was measured 20 % slower)
-constexpr uint32_t ring_capacity(uint32_t slots) { uint32_t r = 64; while (r < slots) r *= 2; return r; }
-
-template <uint32_t SLOTS>
+template <uint32_t SLOTS, uint32_t NQ>
 struct WavePoolLayout {
-    static constexpr uint32_t kRing     = ring_capacity(SLOTS);               // per-queue ring capacity (power of two >= SLOTS)
+    static constexpr uint32_t kRing     = SLOTS;                              // per-queue stack capacity: every slot could sit in one queue
     static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
-    static constexpr uint32_t kOffRing  = kOffAcc + kStripPixels * 3 * 8;     // [kNumOps][kRing] u8
-    static constexpr uint32_t kBytes    = ((kOffRing + kNumOps * kRing + 15) / 16) * 16;
+    static constexpr uint32_t kOffRing  = kOffAcc + kStripPixels * 3 * 8;     // [NQ + 1][kRing] u8
+    static constexpr uint32_t kBytes    = ((kOffRing + (NQ + 1) * kRing + 15) / 16) * 16;
 };
 
-// RARE = false: the host has checked that no sphere selects the checkerboard or the missing-material
-// routine, so their two queues are compiled out of the pick / pop / push loops.
-template <bool RARE> constexpr bool op_in_build(uint32_t k) { return RARE || (k != OP_CHECKER && k != OP_MISSING); }
-
-template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, bool RARE = true>
+template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, uint32_t NQ = 5>
 __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
 {
-    using Lay = WavePoolLayout<SLOTS>;
+    using Lay = WavePoolLayout<SLOTS, NQ>;
+    constexpr uint32_t OP_GEN = NQ, kNumOps = NQ + 1;
+    static_assert(NQ >= 1 && NQ < kMaxQueues, "scatter queues");
     constexpr uint32_t RING = Lay::kRing;
     static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 8 == 0, "slot ids are 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -919,7 +918,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             uint32_t key = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
-                if (!op_in_build<RARE>(k)) continue;
                 const uint32_t kk = (tail[k] << 3) | (7u - k);
                 key = (kk > key) ? kk : key;
             }
@@ -930,7 +928,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             const uint32_t my_begin = depth - my_n;        // the top my_n entries
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
-                if (!op_in_build<RARE>(k)) continue;
                 tail[k] -= (my_k == k) ? my_n : 0u;
             }
 
@@ -988,16 +985,19 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 f3 ndir = rd, att = mk(1, 1, 1);
                 // lanes without a slot run the routine too, on slot 0's (valid) state: their results are never
                 // stored, and leaving them in saves an exec-mask region around every routine
-                if (my_k == OP_LAMBERTIAN) {               // wave-uniform dispatch
+                uint32_t routine = A.queue_routine[0];     // wave-uniform dispatch
+#pragma unroll
+                for (uint32_t k = 1; k < NQ; ++k) routine = (my_k == k) ? A.queue_routine[k] : routine;
+                if (routine == RT_LAMBERTIAN) {
                     if (has) work.add(kCntScatter0);
                     shade_lambertian(A, m, hn, rng, ndir, att);
-                } else if (my_k == OP_METAL) {
+                } else if (routine == RT_METAL) {
                     if (has) work.add(kCntScatter1);
                     shade_metal(A, m, rd, hn, rng, ndir, att);
-                } else if (!RARE || my_k == OP_DIELECTRIC) {
+                } else if (routine == RT_DIELECTRIC) {
                     if (has) work.add(kCntScatter2);
                     shade_dielectric(m, rd, hn, rng, ndir, att);
-                } else if (my_k == OP_CHECKER) {
+                } else if (routine == RT_CHECKER) {
                     if (has) work.add(kCntScatter3);
                     shade_checkerboard(A, m, hp, hn, rng, ndir, att);
                 } else {
@@ -1033,14 +1033,12 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
                 L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), 0u);
             }
-            // next routine, branch-free (after the state is stored: fewer live registers): the op codes ARE
-            // min(material id, 4) and are kept with the sphere.  OP_GEN also when the bounce limit ended the path.
-            static_assert(OP_LAMBERTIAN == 0 && OP_METAL == 1 && OP_DIELECTRIC == 2 && OP_CHECKER == 3 && OP_MISSING == 4, "op = min(id, 4)");
+            // next queue, branch-free (after the state is stored: fewer live registers): the queue of a sphere's
+            // routine is kept with the sphere.  OP_GEN also when the bounce limit ended the path.
             new_op = alive ? (hit ? S.spheres[hit ? nb : 0].op : OP_GEN) : OP_NONE;
             // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
-                if (!op_in_build<RARE>(k)) continue;
                 const unsigned long long mk_ = __ballot(new_op == k);
                 if (new_op == k) L_ring[k * RING + tail[k] + (uint32_t)__popcll(mk_ & lt_mask)] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
@@ -1180,13 +1178,13 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
 }
 
 template <uint32_t T, uint32_t SL, uint32_t MW = 1>
-static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, bool rare, hipStream_t stream)
+static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(T);
     if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, false>, g, b, a, stream);
-    if (!rare) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, false>, g, b, a, stream)
-                            : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, false>, g, b, a, stream);
+    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true>, g, b, a, stream)
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
@@ -1196,27 +1194,37 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 // resident in a CU's 160 KB of LDS.  Measured on config 3: 128 slots (5 waves/SIMD)
 // +2.5 % time; 64 slots -> 68 % lane use, 1.4x; 256 slots -> 8 waves per CU, 1.7x; 88 slots at 7
 // waves per SIMD (72 VGPRs, spills) +10 %.
-static const PoolConfig kPoolConfigs[] = { { 256, 112, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 } };
+static const PoolConfig kPoolConfigs[] = { { 256, 112, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 }, { 256, 96, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
-PoolConfig pool_config(uint32_t i)
+template <uint32_t NQ>
+static uint32_t pool_bytes_per_wave(uint32_t slots)
+{
+    return (slots == 64) ? WavePoolLayout<64, NQ>::kBytes : (slots == 96) ? WavePoolLayout<96, NQ>::kBytes
+         : (slots == 112) ? WavePoolLayout<112, NQ>::kBytes : (slots == 128) ? WavePoolLayout<128, NQ>::kBytes : WavePoolLayout<256, NQ>::kBytes;
+}
+
+// nq = scatter queues of the build that will run (pool_scatter_queues): 3 or 5
+PoolConfig pool_config(uint32_t i, uint32_t nq)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    const uint32_t per_wave = (c.slots == 64) ? WavePoolLayout<64>::kBytes : (c.slots == 112) ? WavePoolLayout<112>::kBytes
-                            : (c.slots == 128) ? WavePoolLayout<128>::kBytes : WavePoolLayout<256>::kBytes;
-    c.lds_bytes = per_wave * (c.threads / 64);
+    c.lds_bytes = (nq <= 3 ? pool_bytes_per_wave<3>(c.slots) : pool_bytes_per_wave<5>(c.slots)) * (c.threads / 64);
     return c;
 }
 
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, bool rare_ops, hipStream_t stream)
+// builds exist for 3 and for 5 scatter queues; the counting build always has 5
+uint32_t pool_scatter_queues(uint32_t n_routines, bool count) { return (!count && n_routines <= 3) ? 3u : 5u; }
+
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     switch (cfg) {
-    case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, rare_ops, stream);
-    case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, rare_ops, stream);
-    case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, rare_ops, stream);
-    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, rare_ops, stream);   // 6 waves per SIMD: <= 80 VGPRs
+    case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, nq, stream);
+    case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, nq, stream);
+    case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, nq, stream);
+    case 4:  return launch_pool_cfg<256, 96, 7>(a, grid_blocks, count, hosek, nq, stream);     // 7 waves per SIMD: <= 72 VGPRs
+    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, nq, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
 }
 
