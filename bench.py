@@ -170,8 +170,13 @@ def main() -> int:
         kmax = k.clone()
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         kernel_ms_max = float(kmax.item())
+        per_rank = torch.zeros(world, dtype=torch.float64, device="cuda")     # every rank's kernel time, so that
+        per_rank[rank] = k[0]                                                  # imbalance is visible
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        kernel_ms_per_rank = [round(float(x), 4) for x in per_rank.tolist()]
     else:
         kernel_ms_max = st["kernel_ms_total"] / max(1, st["launches"])
+        kernel_ms_per_rank = [round(kernel_ms_max, 4)]
     kernel_ms = st["kernel_ms_total"] / max(1, st["launches"])
 
     # one counting launch (outside the timed region) gives the exact work of this rank's launch
@@ -208,7 +213,7 @@ def main() -> int:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: path-traced 3-sphere diffuse+metal+dielectric scene "
+                "workload": "BASELINE configs[2]: path-traced 3-sphere scene, checker-diffuse ground + glass + metal "
                             "(src/main.rs:539-541), 1920x1080, 1000 spp, 8 bounces, gradient sky, seed 0",
                 "width": WIDTH, "height": HEIGHT, "spp": SPP, "num_bounces": BOUNCES, "mode": "pt",
                 "partition": "whole frame" if world == 1 else f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather",
@@ -224,6 +229,7 @@ def main() -> int:
                 "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
+                "kernel_ms_per_rank": kernel_ms_per_rank,
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
                 "flop_per_sample": round(flops / work["samples"], 2),
                 "grays_per_s": round(work["rays"] / (kernel_ms * 1e-3) / 1e9, 3),
