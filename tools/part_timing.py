@@ -13,7 +13,8 @@ ctx = m.Context(0)
 ctx.set_scene(scene_data("three_spheres", w, h))
 base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
 t1 = None
-for world in (1, 2, 4, 8):
+worlds = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 2, 4, 8)
+for world in worlds:
     ts = []
     for part in range(min(world, 3)):
         p = m.multi_gpu.part_params(base, part, world, 4)
