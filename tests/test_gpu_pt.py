@@ -252,6 +252,27 @@ def test_progressive_accumulation_is_exact(gpu_ctx, oracle, kernel):
     assert gpu_ctx.accum_samples() == 0 and not gpu_ctx.accum_read(mk(10)).any()
 
 
+@pytest.mark.parametrize("spp_per_frame", [1, 2, 5, 9])
+def test_few_samples_per_launch_ragged_frame(gpu_ctx, oracle, spp_per_frame):
+    """The reference's interactive loop adds 2 samples per pixel and frame (mod.rs:606-611): such launches run
+    the lane-per-pixel schedule (64 pixels per wave; round-robin units below 8 spp, dispensed above).  A frame
+    whose pixel count is not a multiple of 64 has a ragged last unit; plain and progressive launches, whole
+    frame and one band, must all equal the oracle."""
+    w, h = 70, 33
+    sd = scene_data("main_rs_scene", w, h)
+    gpu_ctx.set_scene(sd)
+    mk = lambda spp, **kw: m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, **kw)   # noqa: E731
+    assert_images_equal(gpu_ctx.render(mk(spp_per_frame)), oracle.render(sd, mk(spp_per_frame)), "one launch")
+    band = mk(spp_per_frame, row_begin=5, row_end=12)
+    assert_images_equal(gpu_ctx.render(band), oracle.render(sd, band), "band")
+    gpu_ctx.accum_reset(mk(spp_per_frame))
+    for f in range(3):
+        gpu_ctx.accum_add(mk(spp_per_frame))
+    assert gpu_ctx.accum_samples() == 3 * spp_per_frame
+    assert np.array_equal(gpu_ctx.accum_read(mk(spp_per_frame)), oracle.render_pt_sums(sd, mk(3 * spp_per_frame)))
+    assert_images_equal(gpu_ctx.accum_resolve(mk(spp_per_frame)), oracle.render(sd, mk(3 * spp_per_frame)), "three frames")
+
+
 def test_raytracer_render_frame_progression(oracle):
     """The reference's progressive loop (mod.rs:626-670): N spp per frame until max, then frames stop adding."""
     scene, cam = m.scenes.three_spheres()

@@ -650,6 +650,15 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
 
+    // few samples per pixel (the reference's interactive loop adds 2 per frame): lane = pixel instead of lane = sample
+    bool by_pixel = pt && !pool && !count && p->spp < mirt::kByPixelMaxSpp;
+    if (const char* e = std::getenv("MIRT_BY_PIXEL")) by_pixel = pt && !pool && !count && e[0] == '1';   // experiment knob
+    a.static_units = 0;
+    if (by_pixel) {
+        a.n_units = (uint32_t)((npix + 63u) / 64u);
+        a.static_units = p->spp < 8u ? 1u : 0u;           // measured crossover (tools/low_spp.py)
+    }
+
     uint32_t blocks;
     if (pool) {
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
@@ -674,7 +683,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
     else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
-    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, stream));
+    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     c->ev_used = ev + 1;
     c->stats_counted = count;

@@ -64,6 +64,7 @@ constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 K
 
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
 constexpr uint32_t kDefaultPoolConfig = 0;
+constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel
 constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cannot keep the pool full: strip kernel
 
 enum CounterSlot : uint32_t {
@@ -91,6 +92,7 @@ struct RenderArgs {
     uint32_t row_begin, tile_rows, n_parts, part;
     uint32_t out_rows;                     // rows this launch writes
     uint32_t n_units;                      // work units (strips) the dispenser hands out
+    uint32_t static_units;                 // lane-per-pixel strip kernel: units dealt round-robin instead of dispensed
     // pool kernel, guided self-scheduling: level l = strips of (kStripPixels >> l) pixels; it starts at unit
     // lvl_unit[l] / pixel lvl_pix[l] (entry kStripLevels = end).  Strips shrink 16 -> 1 pixels towards the end of
     // the frame so that all waves finish within a fraction of a strip of each other.
@@ -109,7 +111,7 @@ struct DeinterleaveArgs {
 
 // launchers (mirt_kernels.hip)
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream);
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, hipStream_t stream);
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);

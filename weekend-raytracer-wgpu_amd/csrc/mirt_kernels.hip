@@ -706,10 +706,62 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
 }
 
 // ------------------------------------------------------------------------------------------
-// render_pt_strip — lane = sample of one pixel, per-lane material switch
+// render_pt_strip — one path per lane, per-lane material switch
 // ------------------------------------------------------------------------------------------
 
+// rayColor wgsl:124-172 for the 64 paths of a wave: returns throughput x sky colour (0 if the bounce limit
+// ended the path).  The loop leaves as soon as no lane of the wave has a live path.
 template <bool COUNT, bool HOSEK, bool GRID>
+MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds& G, bool alive, Rng& rng, f3 ro, f3 rd,
+                          Work<COUNT>& work, uint32_t lane)
+{
+    f3 thr = mk(1, 1, 1);
+    f3 color = mk(0, 0, 0);
+    for (uint32_t bounce = 0; bounce < A.num_bounces; ++bounce) {
+        if (!__ballot(alive)) break;
+        if constexpr (COUNT) {
+            if (lane == 0) work.add(kCntWaveIters);
+            if (alive) work.add(kCntLaneIters);
+        }
+        float closest;
+        int best;
+        if constexpr (GRID) best = nearest_hit_grid(S, G, ro, rd, alive, closest);
+        else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
+        if (alive) {
+            if (best >= 0) {
+                work.add(kCntHits);
+                // sphereIntersection wgsl:431-440
+                const PreparedSphere sp = S.spheres[best];
+                const f3 hp = fma3(closest, rd, ro);
+                const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
+                const PreparedMaterial* m = &S.pmats[sp.material_idx];
+                f3 ndir, att;
+                switch (m->id) {    // scatterRay wgsl:174-202
+                case 0u: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
+                case 1u: work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
+                case 2u: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
+                case 3u: work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
+                default: work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
+                }
+                ro = hp;
+                rd = ndir;
+                thr = thr * att;
+            } else {
+                work.add(kCntSky);
+                color = sky_color<HOSEK>(S, rd);
+                alive = false;
+            }
+        }
+    }
+    return thr * color;
+}
+
+// BY_PIXEL = false: a wave owns a strip of 16 pixels and takes them one at a time, lane = sample
+//                   (s = lane, lane + 64, ...), 64-lane integer reduction per pixel.
+// BY_PIXEL = true : a wave owns 64 consecutive pixels, lane = pixel, and every lane walks its pixel's samples
+//                   in turn -- the launch shape of the reference's interactive loop, which adds 2 samples per
+//                   pixel and frame (mod.rs:606-611): all 64 lanes carry a path whatever spp is, no reduction.
+template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL = false>
 __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -734,86 +786,82 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
     Work<COUNT> work;
     work.clear();
 
+    // BY_PIXEL units are small (64 pixels x a few samples).  With very few samples they are dealt round-robin to
+    // the waves of the grid (A.static_units): one dispenser atomic per unit serialises on its address (measured:
+    // 14 ns each, 0.47 ms for the 32 400 units of a 1080p frame whatever the work) and the units are alike.
+    const uint32_t grid_waves = gridDim.x * (kBlockThreads / 64u);
+    uint32_t my_unit = blockIdx.x * (kBlockThreads / 64u) + (threadIdx.x >> 6);
     for (;;) {
-        const uint32_t strip = next_unit(A, lane);
+        uint32_t strip;
+        if (BY_PIXEL && A.static_units) { strip = my_unit; my_unit += grid_waves; }
+        else strip = next_unit(A, lane);
         if (strip >= A.n_units) break;
-        const uint32_t base = strip * kStripPixels;
-        uint32_t my_px = 0;
-        for (uint32_t p = 0; p < kStripPixels; ++p) {
-            const uint32_t pi = base + p;
-            if (pi >= npix) break;
-            const uint32_t ci = pi / A.width;
-            const uint32_t x = pi - ci * A.width;
+        if constexpr (BY_PIXEL) {
+            const uint32_t pi = strip * 64u + lane;
+            const bool inside = pi < npix;
+            const uint32_t ci = (inside ? pi : 0u) / A.width;
+            const uint32_t x = (inside ? pi : 0u) - ci * A.width;
             const uint32_t y = abs_row(A, ci);
-
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
-            for (uint32_t s0 = 0; s0 < A.spp; s0 += 64) {
-                const uint32_t s = s0 + lane;
-                bool alive = s < A.spp;
+            for (uint32_t s = 0; s < A.spp; ++s) {
                 Rng rng;
                 f3 ro, rd;
-                {   // camera constants are re-read from LDS per batch instead of living in 21 VGPRs (6 waves per SIMD)
+                {
                     const CamRegs C = load_camera(S, A);
                     generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
                 }
-                f3 thr = mk(1, 1, 1);
-                f3 color = mk(0, 0, 0);
+                const f3 c = path_radiance<COUNT, HOSEK, GRID>(A, S, G, inside, rng, ro, rd, work, lane);
+                acc_r += to_fixed(c.x);
+                acc_g += to_fixed(c.y);
+                acc_b += to_fixed(c.z);
+            }
+            if (inside) {
+                if (A.accum) {                   // progressive mode: add the exact sums, resolve later
+                    A.accum[3ull * pi + 0] += acc_r; A.accum[3ull * pi + 1] += acc_g; A.accum[3ull * pi + 2] += acc_b;
+                } else {
+                    A.out[pi] = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
+                                          resolve_channel(acc_b, A.spp, A.flags));
+                }
+            }
+        } else {
+            const uint32_t base = strip * kStripPixels;
+            uint32_t my_px = 0;
+            for (uint32_t p = 0; p < kStripPixels; ++p) {
+                const uint32_t pi = base + p;
+                if (pi >= npix) break;
+                const uint32_t ci = pi / A.width;
+                const uint32_t x = pi - ci * A.width;
+                const uint32_t y = abs_row(A, ci);
 
-                // rayColor wgsl:124-172
-                for (uint32_t bounce = 0; bounce < A.num_bounces; ++bounce) {
-                    if (!__ballot(alive)) break;
-                    if constexpr (COUNT) {
-                        if (lane == 0) work.add(kCntWaveIters);
-                        if (alive) work.add(kCntLaneIters);
+                unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
+                for (uint32_t s0 = 0; s0 < A.spp; s0 += 64) {
+                    const uint32_t s = s0 + lane;
+                    Rng rng;
+                    f3 ro, rd;
+                    {   // camera constants are re-read from LDS per batch instead of living in 21 VGPRs
+                        const CamRegs C = load_camera(S, A);
+                        generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
                     }
-                    float closest;
-                    int best;
-                    if constexpr (GRID) best = nearest_hit_grid(S, G, ro, rd, alive, closest);
-                    else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
-                    if (alive) {
-                        if (best >= 0) {
-                            work.add(kCntHits);
-                            // sphereIntersection wgsl:431-440
-                            const PreparedSphere sp = S.spheres[best];
-                            const f3 hp = fma3(closest, rd, ro);
-                            const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
-                            const PreparedMaterial* m = &S.pmats[sp.material_idx];
-                            f3 ndir, att;
-                            switch (m->id) {    // scatterRay wgsl:174-202
-                            case 0u: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
-                            case 1u: work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
-                            case 2u: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
-                            case 3u: work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
-                            default: work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
-                            }
-                            ro = hp;
-                            rd = ndir;
-                            thr = thr * att;
-                        } else {
-                            work.add(kCntSky);
-                            color = sky_color<HOSEK>(S, rd);
-                            alive = false;
-                        }
+                    const f3 c = path_radiance<COUNT, HOSEK, GRID>(A, S, G, s < A.spp, rng, ro, rd, work, lane);
+                    if (s < A.spp) {
+                        acc_r += to_fixed(c.x);
+                        acc_g += to_fixed(c.y);
+                        acc_b += to_fixed(c.z);
                     }
                 }
-                if (s < A.spp) {
-                    acc_r += to_fixed(thr.x * color.x);
-                    acc_g += to_fixed(thr.y * color.y);
-                    acc_b += to_fixed(thr.z * color.z);
+                acc_r = wave_sum_u64(acc_r);
+                acc_g = wave_sum_u64(acc_g);
+                acc_b = wave_sum_u64(acc_b);
+                if (A.accum) {                   // progressive mode: add the exact sums, resolve later
+                    if (lane == 0) { A.accum[3ull * pi + 0] += acc_r; A.accum[3ull * pi + 1] += acc_g; A.accum[3ull * pi + 2] += acc_b; }
+                } else {
+                    const uint32_t rgba = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
+                                                    resolve_channel(acc_b, A.spp, A.flags));
+                    if (lane == p) my_px = rgba;
                 }
             }
-            acc_r = wave_sum_u64(acc_r);
-            acc_g = wave_sum_u64(acc_g);
-            acc_b = wave_sum_u64(acc_b);
-            if (A.accum) {                       // progressive mode: add the exact sums, resolve later
-                if (lane == 0) { A.accum[3ull * pi + 0] += acc_r; A.accum[3ull * pi + 1] += acc_g; A.accum[3ull * pi + 2] += acc_b; }
-            } else {
-                const uint32_t rgba = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
-                                                resolve_channel(acc_b, A.spp, A.flags));
-                if (lane == p) my_px = rgba;
-            }
+            if (!A.accum && lane < kStripPixels && base + lane < npix) A.out[base + lane] = my_px;
         }
-        if (!A.accum && lane < kStripPixels && base + lane < npix) A.out[base + lane] = my_px;
         work.flush(A.counters, lane);
     }
 }
@@ -1165,12 +1213,18 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t 
     return launch_with_lds(render_parity_kernel, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, hipStream_t stream)
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const dim3 g(grid_blocks), b(kBlockThreads);
     if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
                             : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
+    if (by_pixel) {
+        if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true, true>, g, b, a, stream)
+                                   : launch_with_lds(render_pt_strip_kernel<false, false, true, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, false, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_strip_kernel<false, false, false, true>, g, b, a, stream);
+    }
     if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true>, g, b, a, stream)
                                : launch_with_lds(render_pt_strip_kernel<false, false, true>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, false>, g, b, a, stream)
