@@ -678,7 +678,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     }
     if (blocks == 0) blocks = 1;
 
-    HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), stream));
+    // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
+    const uint32_t launched_waves = blocks * ((pool ? pc.threads : mirt::kBlockThreads) / 64u);
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_work_counter, (int)launched_waves, 1, stream));
     if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
