@@ -66,7 +66,8 @@ def profiled_traffic(kernel: str):
         except (OSError, ValueError):
             continue
         if d.get("kernel_id") == kernel and "hbm_bytes_per_launch" in d.get("derived", {}):
-            best = (d["derived"]["hbm_bytes_per_launch"], f.name)
+            best = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"].get("valu_issue_busy_pct"),
+                    d["derived"].get("valu_lane_utilization_pct"))
     return best
 
 
@@ -226,6 +227,8 @@ def main() -> int:
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 4),
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
+                "valu_busy_pct_profiled": (round(traffic[2], 1) if traffic and traffic[2] is not None else None),
+                "valu_lane_utilization_pct_profiled": (round(traffic[3], 1) if traffic and traffic[3] is not None else None),
                 "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),

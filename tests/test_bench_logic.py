@@ -19,7 +19,8 @@ def test_algorithmic_flops_formula():
 def test_profiled_traffic_lookup_matches_committed_summaries():
     got = bench.profiled_traffic("render_pt_pool_kernel<256,112,false,false>")
     assert got is not None
-    traffic, name = got
+    traffic, name, valu_busy, lane_use = got
+    assert 0.0 < valu_busy <= 100.0 and 0.0 < lane_use <= 100.0
     d = json.loads((ROOT / "profiles" / name).read_text())
     assert d["derived"]["hbm_bytes_per_launch"] == traffic
     # HBM traffic per launch is the 8.3 MB framebuffer plus the strip dispenser's atomics: well under 2x algorithmic
