@@ -12,8 +12,10 @@ w, h, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.ar
 ctx = m.Context(0)
 ctx.set_scene(scene_data("rtiow_final", w, h))
 ref = None
-for name, flags in (("grid (default)", 0), ("flat strip", m.MIRT_FLAG_NO_GRID), ("flat pool", m.MIRT_FLAG_NO_GRID | m.MIRT_FLAG_KERNEL_POOL)):
+for name, flags in (("default", 0), ("strip + grid", m.MIRT_FLAG_KERNEL_STRIP), ("pool + grid", m.MIRT_FLAG_KERNEL_POOL),
+                    ("flat strip", m.MIRT_FLAG_NO_GRID | m.MIRT_FLAG_KERNEL_STRIP), ("flat pool", m.MIRT_FLAG_NO_GRID | m.MIRT_FLAG_KERNEL_POOL)):
     p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags)
+    img = ctx.render(p)
     img = ctx.render(p)
     img = ctx.render(p)
     ms = ctx.stats()["kernel_ms"]

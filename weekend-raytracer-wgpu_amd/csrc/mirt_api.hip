@@ -588,6 +588,19 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
     if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block || !c->fits_flat) pool = false;
+    // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
+    // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
+    const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
+    const bool grid_ok = pt && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
+    const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pc.lds_bytes;
+    const uint32_t pool_grid_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_grid_block ? lds_pool_grid_block : 1)) * (pc.threads / 64u);
+    bool pool_grid = grid_ok && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
+                     lds_pool_grid_block <= (size_t)c->lds_per_block && !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
+                     ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
+                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 12));
+    if (const char* e = std::getenv("MIRT_POOL_GRID")) { if (e[0] == '0') pool_grid = false; }   // experiment knob
+    if (pool_grid) pool = true;
+    const uint32_t resident_pool_waves = pool_grid ? pool_grid_waves_per_cu : pool_waves_per_cu;
 
     mirt::RenderArgs a{};
     a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
@@ -611,7 +624,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // this schedule 99 / 95 / 90 %; strips narrower than 4 pixels lose more to pool fill/drain than they
         // gain.  Narrow strips also need width x spp >= 512 work items to keep a wave's pool busy.
         const char* strip_mode = std::getenv("MIRT_STRIP_MODE");   // experiment knob: "16" = fixed 16-pixel strips
-        const uint64_t waves = (uint64_t)c->cu_count * (pool_waves_per_cu < 32u ? pool_waves_per_cu : 32u);   // resident waves (LDS-bound)
+        const uint64_t waves = (uint64_t)c->cu_count * (resident_pool_waves < 32u ? resident_pool_waves : 32u);   // resident waves (LDS-bound)
         uint32_t min_width = 4;
         while (min_width < mirt::kStripPixels && (uint64_t)min_width * p->spp < 512u) min_width *= 2;
         if (strip_mode && strip_mode[0] == '1') min_width = mirt::kStripPixels;
@@ -640,12 +653,10 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     }
     // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
     // the counting build keeps the reference's flat scan so that its work counters stay comparable)
-    const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
-    const bool use_grid = pt && !pool && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID) &&
-                          scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block;
+    const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block);
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
-    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes) : (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
+    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pc.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");

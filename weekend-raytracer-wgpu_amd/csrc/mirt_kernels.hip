@@ -438,6 +438,21 @@ MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, 
     }
 }
 
+// copy the grid (header + 16-bit CSR lists) behind the scene tables in LDS; all threads of the block take part
+MIRT_DEV GridLds stage_grid(const RenderArgs& A, unsigned char* gdst)
+{
+    for (uint32_t i = threadIdx.x; i < A.grid_bytes / 16; i += blockDim.x)
+        reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(A.grid)[i];
+    __syncthreads();
+    GridLds G;
+    G.h = reinterpret_cast<const GridHeader*>(gdst);
+    const unsigned short* base = reinterpret_cast<const unsigned short*>(gdst);
+    G.big = base + G.h->off_big;
+    G.start = base + G.h->off_start;
+    G.items = base + G.h->off_items;
+    return G;
+}
+
 MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool alive, float& closest_out)
 {
     const float a = dot(rd, rd);
@@ -772,17 +787,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
     // so that LDS holds only what every sphere TEST reads, and more waves fit a CU
     const SceneLds S = stage_scene<true, !GRID>(A, smem, HOSEK);
     GridLds G{};
-    if constexpr (GRID) {                                  // stage the grid behind the scene tables
-        unsigned char* gdst = smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, false);
-        for (uint32_t i = threadIdx.x; i < A.grid_bytes / 16; i += blockDim.x)
-            reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(A.grid)[i];
-        __syncthreads();
-        G.h = reinterpret_cast<const GridHeader*>(gdst);
-        const unsigned short* base = reinterpret_cast<const unsigned short*>(gdst);
-        G.big = base + G.h->off_big;
-        G.start = base + G.h->off_start;
-        G.items = base + G.h->off_items;
-    }
+    if constexpr (GRID) G = stage_grid(A, smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, false));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t npix = A.out_rows * A.width;
 
@@ -899,7 +904,9 @@ struct WavePoolLayout {
     static constexpr uint32_t kBytes    = ((kOffRing + (NQ + 1) * kRing + 15) / 16) * 16;
 };
 
-template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, uint32_t NQ = 5>
+// GRID = true (many-sphere scenes): nearest hit through the uniform grid staged behind the spheres; the material
+// table stays in global memory / L2 as in the strip kernel's grid build, and the pools follow the grid in LDS.
+template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, uint32_t NQ = 5, bool GRID = false>
 __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
 {
     using Lay = WavePoolLayout<SLOTS, NQ>;
@@ -908,11 +915,13 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     constexpr uint32_t RING = Lay::kRing;
     static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 8 == 0, "slot ids are 8 bit");
     extern __shared__ __align__(16) unsigned char smem[];
-    const SceneLds S = stage_scene<true>(A, smem, HOSEK);
+    const SceneLds S = stage_scene<true, !GRID>(A, smem, HOSEK);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t scene_bytes = (uint32_t)scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK);
+    uint32_t scene_bytes = (uint32_t)scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, !GRID);
+    GridLds G{};
+    if constexpr (GRID) { G = stage_grid(A, smem + scene_bytes); scene_bytes += A.grid_bytes; }
     unsigned char* pool = smem + scene_bytes + wave * Lay::kBytes;
     uint4* const L_state = reinterpret_cast<uint4*>(pool + Lay::kOffState);
     unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
@@ -1064,7 +1073,9 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             const bool trace = alive && bounce < A.num_bounces;
             if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
             float closest;
-            const int nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
+            int nb;
+            if constexpr (GRID) nb = nearest_hit_grid(S, G, ro, rd, trace, closest);
+            else nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
             const bool hit = trace && nb >= 0;
             if (hit) work.add(kCntHits);
             miss = (trace && nb < 0) ? 1u : 0u;            // left the scene: OP_GEN adds throughput x sky
@@ -1240,6 +1251,17 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
 
+// grid build of the default pool geometry: LDS (scene + grid + pools) bounds it to a few blocks per CU, so the
+// register budget is not the limit
+static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool hosek, uint32_t nq, hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(256);
+    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 3, true>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 3, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 5, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 5, true>, g, b, a, stream);
+}
+
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
 // (6 waves per SIMD = 24 per CU); 112 slots x 48 B + rings + accumulators = 6.4 KB per wave keeps all 24
 // resident in a CU's 160 KB of LDS.  Measured on config 3: 128 slots (5 waves/SIMD)
@@ -1270,6 +1292,7 @@ uint32_t pool_scatter_queues(uint32_t n_routines, bool count) { return (!count &
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
+    if (a.grid) return launch_pool_grid(a, grid_blocks, hosek, nq, stream);     // host: default geometry, not counting
     switch (cfg) {
     case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, nq, stream);
     case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, nq, stream);
