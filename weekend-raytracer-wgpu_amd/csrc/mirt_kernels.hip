@@ -870,11 +870,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
     }
 }
 
-// shading routines ("ops") a path can wait for: the five scatter routines of scatterRay
-// (wgsl:174-314) and OP_GEN = finish the path (add throughput x sky) + start the next work item
-// Routine ids (= min(GpuMaterial.id, 4)).  A scene's routines are numbered densely on the host (queue q runs
-// routine RenderArgs.queue_routine[q], PreparedSphere.op holds q), so a kernel built for NQ scatter queues
-// has NQ + 1 queues: 0..NQ-1 scatter, NQ = OP_GEN.
+// Shading routines a path can wait for: the five scatter routines of scatterRay (wgsl:174-314), identified by
+// min(GpuMaterial.id, 4), and OP_GEN = finish the path (add throughput x sky) + start the next work item.
+// A scene's routines are numbered densely on the host (queue q runs routine RenderArgs.queue_routine[q],
+// PreparedSphere.op holds q), so a kernel built for NQ scatter queues has NQ + 1 queues: 0..NQ-1 scatter,
+// NQ = OP_GEN.
 constexpr uint32_t RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2, RT_CHECKER = 3;
 constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 
@@ -887,14 +887,15 @@ constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 // material switch runs every routine present.  Here a wave instead keeps SLOTS paths in LDS:
 //   q0 = {hit point (or nothing after a miss), sphere | pixel << 12 | bounce << 16 | has_miss << 24}
 //   q1 = {incoming direction rd, rng}   q2 = {throughput, -}                 (48 B, ds_*_b128)
-// and every slot id sits in exactly one of six ring queues — the routine ("op") its path waits
-// for.  Each step the wave pops up to 64 ids from its FULLEST queue, gathers those paths, runs
-// that one routine for all lanes, then the common tail (bounce limit, nearest hit,
-// classification) and pushes each id to the queue of its next op.  A wave owns its pool outright:
-// a strip of kStripPixels pixels = strip_pixels x spp work items (item = sample * strip_pixels +
-// pixel), their 64-bit accumulators, the item counter and all queue heads/tails in SGPRs.
-// Nothing is shared between waves after the scene has been staged: no barrier, no inter-wave
-// atomic.  (A block-level pool with barriers was measured 20 % slower)
+// and every slot id sits in exactly one queue — that of the routine its path waits for.  Each step the wave
+// pops up to 64 ids from its DEEPEST queue, gathers those paths, runs that one routine for all lanes, then
+// the common tail (bounce limit, nearest hit, next queue) and pushes each id to the queue of its next
+// routine.  The queues are stacks of 8-bit ids: the order of service cannot change the image (exact integer
+// accumulation), so a queue is described by its depth alone.  A wave owns its pool outright: a strip of up to
+// kStripPixels pixels = strip_pixels x spp work items (item = sample * strip_pixels + pixel), their 64-bit
+// accumulators, the item counter and all queue depths in SGPRs.  Nothing is shared between waves after the
+// scene has been staged: no barrier, no inter-wave atomic.  (A block-level pool with barriers was measured
+// 20 % slower)
 template <uint32_t SLOTS, uint32_t NQ>
 struct WavePoolLayout {
     static constexpr uint32_t kRing     = SLOTS;                              // per-queue stack capacity: every slot could sit in one queue
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_state[s * 3].w = 0u; }
         if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
         // Each queue is a STACK of slot ids (order of service is free: the image does not depend on it), so a
-        // queue is described by its depth alone -- six SGPRs, no heads, no index wrap.
+        // queue is described by its depth alone -- NQ + 1 SGPRs, no heads, no index wrap.
         uint32_t tail[kNumOps];                            // wave-uniform (SGPRs)
 #pragma unroll
         for (uint32_t k = 0; k < kNumOps; ++k) tail[k] = (k == OP_GEN) ? SLOTS : 0u;
