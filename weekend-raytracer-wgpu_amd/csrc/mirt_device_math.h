@@ -68,6 +68,22 @@ MIRT_DEV float sqrt_where(float x, bool want)
     return s;
 }
 
+// sqrt_ for arguments known to lie in [0, 1] (a uniform variate, 1 - variate): the upper range check is moot.
+MIRT_DEV float sqrt_unit(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    float s = __builtin_fmaf(d, h, g);
+    const bool odd = !(x >= 0x1p-100f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
+        asm volatile("; sqrt_unit: IEEE expansion" ::);
+        s = odd ? sqrt_ieee(x) : s;
+    }
+    return s;
+}
+
 MIRT_DEV float rcp_(float x)           // == 1.0f / x bit for bit
 {
     const float y0 = __builtin_amdgcn_rcpf(x);
@@ -235,7 +251,26 @@ MIRT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); 
 MIRT_DEV f3 fma3(float s, f3 a, f3 b) { return mk(fma_(s, a.x, b.x), fma_(s, a.y, b.y), fma_(s, a.z, b.z)); }
 // path-traced dot: fma(az,bz, fma(ay,by, ax*bx))
 MIRT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-MIRT_DEV f3 normalize(f3 a) { return rcp_(sqrt_(dot(a, a))) * a; }
+// 1 / sqrt(x) as two correctly rounded steps, == rcp_(sqrt_(x)) bit for bit, behind ONE range check: for
+// 2^-100 <= x <= 2^100 the square root lies in [2^-50, 2^50], inside the reciprocal's fast range too.
+MIRT_DEV float inv_sqrt_2step(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    const float s = __builtin_fmaf(d, h, g);                   // sqrt_(x)
+    const float y0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, y0, 1.0f);
+    float r = __builtin_fmaf(y0, e, y0);                       // rcp_(s)
+    const bool odd = !(x >= 0x1p-100f && x <= 0x1p100f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
+        asm volatile("; inv_sqrt_2step: IEEE expansion" ::);
+        r = odd ? rcp_ieee(sqrt_ieee(x)) : r;
+    }
+    return r;
+}
+MIRT_DEV f3 normalize(f3 a) { return inv_sqrt_2step(dot(a, a)) * a; }
 // parity-mode dot (nalgebra, no fusion): (a0*b0 + a1*b1) + a2*b2
 MIRT_DEV float dot_nofma(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 

@@ -342,7 +342,7 @@ MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x
     rng.state = jenkins_hash((pixel_index ^ jenkins_hash(sample + 1u)) ^ A.seed_mix);
     const float u = ((float)x + rng.next()) * C.inv_w;
     const float v = 1.0f - ((float)y + rng.next()) * C.inv_h;
-    const float lr = sqrt_(rng.next());
+    const float lr = sqrt_unit(rng.next());
     const SinCos la = sincos_(kTwoPi * rng.next());
     const float lpx = C.lens_radius * (lr * la.c);
     const float lpy = C.lens_radius * (lr * la.s);
@@ -580,8 +580,8 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
 {
     const float r1 = rng.next();
     const float r2 = rng.next();
-    const float sqrt_r2 = sqrt_(r2);
-    const float z = sqrt_(1.0f - r2);
+    const float sqrt_r2 = sqrt_unit(r2);
+    const float z = sqrt_unit(1.0f - r2);
     const SinCos sc = sincos_(kTwoPi * r1);
     const float lx = sc.c * sqrt_r2;
     const float ly = sc.s * sqrt_r2;
@@ -1133,6 +1133,9 @@ __global__ __launch_bounds__(256) void selftest_math_kernel(unsigned long long* 
         const float x = from_bits((uint32_t)i);
         bad_sqrt += bits(sqrt_(x)) != bits(sqrt_ieee(x));
         bad_rcp += bits(rcp_(x)) != bits(rcp_ieee(x));
+        // the derived forms, on their domains: sqrt_unit on [0, 1]; inv_sqrt_2step == rcp(sqrt(x)) on [0, +inf]
+        if (x >= 0.0f && x <= 1.0f) bad_sqrt += bits(sqrt_unit(x)) != bits(sqrt_ieee(x));
+        if (x >= 0.0f) bad_rcp += bits(inv_sqrt_2step(x)) != bits(rcp_ieee(sqrt_ieee(x)));
     }
     bad_sqrt = wave_sum_u64(bad_sqrt);
     bad_rcp = wave_sum_u64(bad_rcp);
