@@ -51,23 +51,6 @@ MIRT_DEV float sqrt_(float x)
     return s;
 }
 
-// sqrt_ for callers that only use the result on lanes where `want` holds (and x > 0 there): the other
-// lanes may carry negative or NaN arguments without sending the wave down the IEEE expansion.
-MIRT_DEV float sqrt_where(float x, bool want)
-{
-    const float y = __builtin_amdgcn_rsqf(x);
-    const float g = x * y;
-    const float h = 0.5f * y;
-    const float d = __builtin_fmaf(-g, g, x);
-    float s = __builtin_fmaf(d, h, g);
-    const bool odd = want && !(x >= 0x1p-100f && x <= 0x1p100f);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
-        asm volatile("; sqrt_where: IEEE expansion" ::);
-        s = odd ? sqrt_ieee(x) : s;
-    }
-    return s;
-}
-
 // sqrt_ for arguments known to lie in [0, 1] (a uniform variate, 1 - variate): the upper range check is moot.
 MIRT_DEV float sqrt_unit(float x)
 {
@@ -82,6 +65,32 @@ MIRT_DEV float sqrt_unit(float x)
         s = odd ? sqrt_ieee(x) : s;
     }
     return s;
+}
+
+// sqrt_ for callers that only use the result on lanes where `want` holds, with 0 < x <= 1 there (the
+// refraction discriminant): the other lanes may carry negative or NaN arguments without sending the wave
+// down the IEEE expansion.
+MIRT_DEV float sqrt_unit_where(float x, bool want)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    float s = __builtin_fmaf(d, h, g);
+    const bool odd = want && !(x >= 0x1p-100f);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0ull, 0)) {
+        asm volatile("; sqrt_unit_where: IEEE expansion" ::);
+        s = odd ? sqrt_ieee(x) : s;
+    }
+    return s;
+}
+
+// 1/x for 2^-100 <= |x| <= 2^100 guaranteed by the caller: the fast sequence alone (no range check).
+MIRT_DEV float rcp_in_range(float x)
+{
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    return __builtin_fmaf(y0, e, y0);
 }
 
 MIRT_DEV float rcp_(float x)           // == 1.0f / x bit for bit

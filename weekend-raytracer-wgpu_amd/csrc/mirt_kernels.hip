@@ -586,7 +586,7 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
     const float lx = sc.c * sqrt_r2;
     const float ly = sc.s * sqrt_r2;
     const float sg = (n.z >= 0.0f) ? 1.0f : -1.0f;
-    const float aa = -rcp_(sg + n.z);                  // -(1/x) == -1/x exactly
+    const float aa = -rcp_in_range(sg + n.z);          // -(1/x) == -1/x exactly; |sg + n.z| lies in [1, 2] for a unit normal
     const float bb = n.x * n.y * aa;
     const f3 U = mk(fma_(sg * n.x, n.x * aa, 1.0f), sg * bb, -(sg * n.x));
     const f3 V = mk(bb, fma_(n.y, n.y * aa, sg), -n.y);
@@ -632,7 +632,7 @@ MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng
     // both outcomes in straight-line code and a select (no divergent if/else): total internal reflection
     // keeps the reflected direction and does NOT consume the Schlick draw
     const bool refracts = disc > 0.0f;
-    const float sq = refracts ? sqrt_where(disc, refracts) : 0.0f;     // 0 keeps the unused lanes finite
+    const float sq = refracts ? sqrt_unit_where(disc, refracts) : 0.0f;   // disc <= 1; 0 keeps the unused lanes finite
     const f3 q = fma3(-dt, outn, uvn);
     const f3 refr = normalize(fma3(-sq, outn, ratio * q));
     const f3 refl = reflect3(rd, hn);
