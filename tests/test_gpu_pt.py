@@ -4,6 +4,8 @@ and the work counters — every branch decision of every path — equal."""
 import sys
 from pathlib import Path
 
+import os
+
 import numpy as np
 import pytest
 
@@ -179,6 +181,48 @@ def test_missing_material_id_and_every_material(gpu_ctx, oracle):
     os_ = oracle.stats()
     assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
     assert all(n > 0 for n in gs["scatter"]), gs["scatter"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MIRT_FUZZ_SEEDS", "8"))))     # deeper runs: MIRT_FUZZ_SEEDS=300
+def test_random_scenes_materials_and_cameras(gpu_ctx, oracle, seed):
+    """Fuzz of the path-traced mode: random sphere soups (overlapping, nested, behind the camera, huge), random
+    material tables (every routine incl. the missing-material one, random fuzz / refraction index, 1x1 and
+    image textures), random cameras (aperture 0 and wide, any pose).  Every schedule of the library must give
+    the oracle's exact 64-bit sums -- with 1 to 5 routines present the pool kernel's 4- and 6-queue builds,
+    the lane-per-sample and the lane-per-pixel strip schedules are all exercised."""
+    rng = np.random.default_rng(500 + seed)
+    T = m.Texture
+    img = (rng.random((6, 10, 3)) * 255).astype(np.uint8)
+
+    def tex():
+        return T.new_from_rgb8(img[: int(rng.integers(1, 6)), : int(rng.integers(1, 10))]) if rng.random() < 0.3 \
+            else T.new_from_color(tuple(float(x) for x in rng.random(3)))
+
+    kinds = int(rng.integers(1, 6))                       # how many different routines this scene may use
+    makers = [lambda: m.Material.Lambertian(tex()), lambda: m.Material.Metal(tex(), float(rng.random())),
+              lambda: m.Material.Dielectric(float(rng.uniform(0.6, 2.4))),
+              lambda: m.Material.Checkerboard(even=tex(), odd=tex())]
+    order = list(rng.permutation(5))[:kinds]              # 4 = the missing-material routine
+    mats = [makers[int(rng.choice([k for k in order if k < 4] or [0]))]() for _ in range(int(rng.integers(1, 7)))]
+    gm, texels = m.flatten_materials(mats)
+    if 4 in order:
+        gm.append(m._abi.MirtMaterial(int(rng.integers(4, 100)), m.TextureDescriptor.empty(), m.TextureDescriptor.empty(), 0.0))
+    n = int(rng.integers(1, 24))
+    spheres = [m.Sphere.new(rng.normal(size=3) * 3, float(rng.uniform(0.05, 2.0) if rng.random() < 0.9 else 200.0),
+                            int(rng.integers(0, len(gm)))).to_c() for _ in range(n)]
+    w, h = int(rng.integers(24, 90)), int(rng.integers(16, 60))
+    fc = m.FlyCameraController(rng.normal(size=3).astype(np.float32) * 4, m.Angle.degrees(float(rng.uniform(-180, 180))),
+                               m.Angle.degrees(float(rng.uniform(-60, 60))), float(rng.uniform(20, 90)),
+                               0.0 if rng.random() < 0.4 else float(rng.uniform(0.0, 1.0)), float(rng.uniform(1, 10)))
+    sd = m.SceneData(m.GpuCamera.new(fc.renderer_camera(), (w, h)).c, spheres, gm, texels)
+    gpu_ctx.set_scene(sd)
+    for spp, flags in ((3, 0), (11, 0), (64, m.MIRT_FLAG_KERNEL_STRIP), (64, m.MIRT_FLAG_KERNEL_POOL), (50, 0)):
+        bounces = int(rng.integers(1, 10))
+        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, seed=seed, flags=flags)
+        gpu_ctx.accum_reset(p)
+        gpu_ctx.accum_add(p)
+        want = oracle.render_pt_sums(sd, m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, seed=seed))
+        assert np.array_equal(gpu_ctx.accum_read(p), want), f"seed {seed}: {n} spheres, routines {order}, {w}x{h}, spp {spp}, flags {flags:#x}"
 
 
 def test_tiles_and_sample_split_reassemble(gpu_ctx):
