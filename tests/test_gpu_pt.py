@@ -1,10 +1,9 @@
 """Parity proper (MI355X): path-traced mode (behaviours of reference src/raytracer/raytracer.wgsl)
 through the C ABI against the CPU oracle: RGBA8 u8-exact, linear (un-tonemapped) output u8-exact,
 and the work counters — every branch decision of every path — equal."""
+import os
 import sys
 from pathlib import Path
-
-import os
 
 import numpy as np
 import pytest
