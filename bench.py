@@ -137,7 +137,10 @@ def main() -> int:
     ctx.set_scene(sd)                                   # inputs resident in HBM before the timed region
     base = m.make_params(WIDTH, HEIGHT, SPP, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES,
                          flags=int(os.environ.get("MIRT_BENCH_FLAGS", "0"), 0))      # e.g. 0x10 strip / 0x20 pool (A/B runs)
-    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows)
+    # N > 1: the gather of frame i overlaps the render of frame i+1 (double-buffered parts, async collective);
+    # every frame is complete on rank 0 before the timed region ends (flush).  MIRT_BENCH_PIPELINE=0: one frame at a time.
+    pipelined = world > 1 and os.environ.get("MIRT_BENCH_PIPELINE", "1") != "0"
+    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined)
 
     def barrier():
         if world > 1:
@@ -152,6 +155,7 @@ def main() -> int:
 
     for _ in range(args.warmup):
         frame.step()
+    frame.flush()
     torch.cuda.synchronize()
     ctx.stats()                                         # drain the event pool: the timed region starts clean
     barrier()
@@ -159,6 +163,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame.step()
+    frame.flush()                                       # all K frames assembled on rank 0
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -217,7 +222,8 @@ def main() -> int:
                 "workload": "BASELINE configs[2]: path-traced 3-sphere scene, checker-diffuse ground + glass + metal "
                             "(src/main.rs:539-541), 1920x1080, 1000 spp, 8 bounces, gradient sky, seed 0",
                 "width": WIDTH, "height": HEIGHT, "spp": SPP, "num_bounces": BOUNCES, "mode": "pt",
-                "partition": "whole frame" if world == 1 else f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather",
+                "partition": "whole frame" if world == 1 else f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather per frame"
+                             + (" (overlapping the next frame's render)" if pipelined else ""),
             },
             "roofline": {
                 "bound": "valu_fp32",

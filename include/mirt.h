@@ -252,8 +252,9 @@ int mirt_ctx_set_camera(MirtContext* ctx, const MirtGpuCamera* camera);
 int mirt_ctx_render(MirtContext* ctx, const MirtParams* params, uint8_t* out_rgba8, size_t out_len);
 
 /* Render into DEVICE memory `d_out_rgba8` (same layout) asynchronously on `hip_stream`
- * (a hipStream_t passed as void*; NULL = the context's own stream).  No host sync: the
- * caller orders later work on the same stream (RCCL gather, D2H).  Used by bench.py and
+ * (a hipStream_t passed as void*; NULL = the context's own non-blocking stream; to run on the
+ * default stream pass hipStreamLegacy, not 0).  No host sync: the caller orders later work on
+ * the same stream (RCCL gather, D2H).  Used by bench.py and
  * the multi-GPU path so the framebuffer never leaves HBM before the collective. */
 int mirt_ctx_render_device(MirtContext* ctx, const MirtParams* params, void* d_out_rgba8,
                            size_t out_len, void* hip_stream);

@@ -2,6 +2,7 @@
 lifecycle, device-memory rendering into a torch tensor on torch's stream, device de-interleave,
 one-shot mirt_render."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -135,6 +136,46 @@ def test_render_into_torch_tensor_and_device_deinterleave(gpu_ctx):
     assert_images_equal(out.cpu().numpy(), want, "device de-interleave")
     st = gpu_ctx.stats()
     assert st["launches"] == world + 1 and st["kernel_ms_total"] >= st["kernel_ms"] > 0
+
+
+def test_collective_path_on_a_single_rank_rccl_group(gpu_ctx):
+    """One GPU per box, so the N > 1 bench path cannot run here; what can is its plumbing: an RCCL process group
+    of one rank drives TiledFrame's collective code -- synchronous gather, and the pipelined variant (async
+    gather into double buffers, stream-level waits, flush) -- and every frame must arrive intact, also when the
+    content changes from step to step."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu_ctx.device))
+    except Exception as e:  # pragma: no cover - environment without RCCL
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        w, h, spp = 160, 90, 16
+        gpu_ctx.set_scene(scene_data("three_spheres", w, h))
+        for pipelined in (False, True):
+            base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
+            fr = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1, pipelined=pipelined, _rehearse_single_rank=True)
+            for seed in range(5):
+                fr.params.seed = seed
+                fr.step()
+            fr.flush()
+            t = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            torch.cuda.synchronize()
+            want = gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, seed=4))
+            assert_images_equal(fr.frame.cpu().numpy(), want, f"last of five frames, pipelined={pipelined}")
+            assert float(t.item()) == 2.5
+    finally:
+        dist.destroy_process_group()
 
 
 def test_set_camera_only(gpu_ctx, oracle):

@@ -59,6 +59,22 @@ def params_out_row_index(params: _abi.MirtParams, i: int) -> int:
     return int(lib().mirt_params_out_row_index(C.byref(params), i))
 
 
+HIP_STREAM_LEGACY = 1      # hipStreamLegacy ((hipStream_t)1, hip_runtime_api.h): the default ("null") stream by handle
+
+
+def _stream_arg(stream: Optional[int]):
+    """`stream` of the *_device / accum_add wrappers -> the C ABI's void* hip_stream.
+
+    None  -> NULL: the context's own (non-blocking) stream.
+    int h -> that hipStream_t; h == 0 is the DEFAULT stream (what `torch.cuda.current_stream().cuda_stream`
+             returns unless a side stream is current) and is passed as hipStreamLegacy, because a NULL pointer
+             already means "the context's own stream" in the C ABI -- sending 0 through would silently move the
+             work to a stream that nothing the caller queues afterwards (an RCCL collective, a D2H copy) waits for."""
+    if stream is None:
+        return None
+    return C.c_void_p(int(stream) if int(stream) != 0 else HIP_STREAM_LEGACY)
+
+
 class Context:
     """mirt_ctx_* : one per HIP device; owns the device-resident scene."""
 
@@ -100,23 +116,22 @@ class Context:
         check(lib().mirt_ctx_render(self._h, C.byref(params), out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
-    def render_device(self, params: _abi.MirtParams, d_ptr: int, nbytes: int, stream: int = 0) -> None:
-        """Render asynchronously into device memory (e.g. a torch uint8 CUDA tensor's data_ptr())."""
-        check(lib().mirt_ctx_render_device(self._h, C.byref(params), C.c_void_p(d_ptr), nbytes,
-                                           C.c_void_p(stream) if stream else None))
+    def render_device(self, params: _abi.MirtParams, d_ptr: int, nbytes: int, stream: Optional[int] = None) -> None:
+        """Render asynchronously into device memory (e.g. a torch uint8 CUDA tensor's data_ptr()) on `stream`
+        (see _stream_arg: None = the context's stream, 0 = the default stream, else a hipStream_t handle)."""
+        check(lib().mirt_ctx_render_device(self._h, C.byref(params), C.c_void_p(d_ptr), nbytes, _stream_arg(stream)))
 
     def deinterleave_device(self, params: _abi.MirtParams, d_parts: int, part_stride: int, d_out: int,
-                            out_nbytes: int, stream: int = 0) -> None:
+                            out_nbytes: int, stream: Optional[int] = None) -> None:
         check(lib().mirt_ctx_deinterleave_device(self._h, C.byref(params), C.c_void_p(d_parts), part_stride,
-                                                 C.c_void_p(d_out), out_nbytes,
-                                                 C.c_void_p(stream) if stream else None))
+                                                 C.c_void_p(d_out), out_nbytes, _stream_arg(stream)))
 
     # ---- progressive accumulation (RenderProgress::next_frame + the shader's image buffer) ----
     def accum_reset(self, params: _abi.MirtParams) -> None:
         check(lib().mirt_ctx_accum_reset(self._h, C.byref(params)))
 
-    def accum_add(self, params: _abi.MirtParams, stream: int = 0) -> None:
-        check(lib().mirt_ctx_accum_add(self._h, C.byref(params), C.c_void_p(stream) if stream else None))
+    def accum_add(self, params: _abi.MirtParams, stream: Optional[int] = None) -> None:
+        check(lib().mirt_ctx_accum_add(self._h, C.byref(params), _stream_arg(stream)))
 
     def accum_samples(self) -> int:
         return int(lib().mirt_ctx_accum_samples(self._h))

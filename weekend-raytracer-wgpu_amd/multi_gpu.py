@@ -67,33 +67,87 @@ def assemble_host(parts: np.ndarray, base: _abi.MirtParams, world: int, tile_row
 
 
 class TiledFrame:
-    """Per-rank state of the multi-GPU render of one frame on GPUs."""
+    """Per-rank state of the multi-GPU render of one frame on GPUs.
 
-    def __init__(self, ctx: Context, base: _abi.MirtParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS):
+    `pipelined=True` (world > 1) double-buffers the part buffers and issues the gather with `async_op=True`:
+    the gather of frame i travels while frame i+1 renders, and rank 0 de-interleaves frame i after that.  Ranks
+    then no longer meet once per frame; `flush()` completes the frames still in flight."""
+
+    def __init__(self, ctx: Context, base: _abi.MirtParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS,
+                 pipelined: bool = False, _rehearse_single_rank: bool = False):
         import torch
 
         self.ctx, self.base, self.rank, self.world, self.tile_rows = ctx, base, rank, world, tile_rows
         self.params = part_params(base, rank, world, tile_rows)
         self.rows = params_out_rows(self.params)
         self.max_rows = max_part_rows(base, world, tile_rows)
+        self._rehearse = _rehearse_single_rank and world == 1       # drive the collective path with a 1-rank group
+        self.pipelined = pipelined and (world > 1 or self._rehearse)
         dev = torch.device("cuda", ctx.device)
-        self.local = torch.zeros((self.max_rows, base.width, 4), dtype=torch.uint8, device=dev)
+        n_buf = 2 if self.pipelined else 1
+        self.locals = [torch.zeros((self.max_rows, base.width, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        self.local = self.locals[0]
         self.frame = (torch.zeros((band_rows(base), base.width, 4), dtype=torch.uint8, device=dev)
                       if rank == 0 else None)
-        self.parts = (torch.zeros((world, self.max_rows, base.width, 4), dtype=torch.uint8, device=dev)
-                      if rank == 0 and world > 1 else None)
+        collective = world > 1 or self._rehearse
+        self.parts_bufs = ([torch.zeros((world, self.max_rows, base.width, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+                           if rank == 0 and collective else None)
+        self.parts = self.parts_bufs[0] if self.parts_bufs else None
+        self._pending = [None] * n_buf
+        self._k = 0
+
+    def _assemble(self, parts, stream):
+        if self._rehearse:
+            self.frame.copy_(parts[0][: self.frame.shape[0]])
+            return
+        self.ctx.deinterleave_device(part_params(self.base, 0, self.world, self.tile_rows), parts.data_ptr(),
+                                     self.local.numel(), self.frame.data_ptr(), self.frame.numel(), stream)
+
+    def _retire(self, b: int, stream) -> None:
+        """Frame in buffer b: its gather has completed (stream-level wait); rank 0 assembles it."""
+        self._pending[b].wait()
+        self._pending[b] = None
+        if self.rank == 0:
+            self._assemble(self.parts_bufs[b], stream)
 
     def step(self):
-        """Render this rank's tiles, gather to rank 0, assemble.  Returns the frame tensor on rank 0."""
+        """Render this rank's tiles, gather to rank 0, assemble.  Returns the frame tensor on rank 0
+        (pipelined: the frame of the PREVIOUS step; call flush() after the last one)."""
+        import torch
+        import torch.distributed as dist
+
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.world == 1 and not self._rehearse:
+            self.ctx.render_device(self.params, self.frame.data_ptr(), self.frame.numel(), stream)
+            return self.frame
+        if not self.pipelined:
+            self.ctx.render_device(self.params, self.local.data_ptr(), self.rows * self.base.width * 4, stream)
+            if self._rehearse:
+                dist.gather(self.local, list(self.parts.unbind(0)), dst=0)
+                parts = self.parts
+            else:
+                parts = gather_parts(self.local, self.rank, self.world, dst=0, out=self.parts)
+            if self.rank == 0:
+                self._assemble(parts, stream)
+            return self.frame
+        b = self._k & 1
+        if self._pending[b] is not None:                   # frame k-2 (normally retired one step ago)
+            self._retire(b, stream)
+        self.ctx.render_device(self.params, self.locals[b].data_ptr(), self.rows * self.base.width * 4, stream)
+        gather_list = list(self.parts_bufs[b].unbind(0)) if self.rank == 0 else None
+        self._pending[b] = dist.gather(self.locals[b], gather_list, dst=0, async_op=True)
+        if self._pending[b ^ 1] is not None:               # frame k-1: its gather had a whole render to complete
+            self._retire(b ^ 1, stream)
+        self._k += 1
+        return self.frame
+
+    def flush(self):
+        """Complete the frames still in flight (pipelined mode); older first."""
         import torch
 
         stream = torch.cuda.current_stream().cuda_stream
-        if self.world == 1:
-            self.ctx.render_device(self.params, self.frame.data_ptr(), self.frame.numel(), stream)
-            return self.frame
-        self.ctx.render_device(self.params, self.local.data_ptr(), self.rows * self.base.width * 4, stream)
-        parts = gather_parts(self.local, self.rank, self.world, dst=0, out=self.parts)
-        if self.rank == 0:
-            self.ctx.deinterleave_device(part_params(self.base, 0, self.world, self.tile_rows), parts.data_ptr(),
-                                         self.local.numel(), self.frame.data_ptr(), self.frame.numel(), stream)
+        if self.pipelined:
+            for b in ((self._k & 1), (self._k & 1) ^ 1):
+                if self._pending[b] is not None:
+                    self._retire(b, stream)
         return self.frame
