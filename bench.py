@@ -132,6 +132,10 @@ def main() -> int:
 
     import weekend_raytracer_wgpu_amd as m
 
+    # everything below is queued on ONE non-default stream: renders (through the C ABI), the RCCL gather (which
+    # orders itself against torch's current stream) and the de-interleave
+    torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
+
     sd = build_scene(m)
     ctx = m.Context(local_rank)
     ctx.set_scene(sd)                                   # inputs resident in HBM before the timed region

@@ -160,19 +160,21 @@ def test_collective_path_on_a_single_rank_rccl_group(gpu_ctx):
     try:
         w, h, spp = 160, 90, 16
         gpu_ctx.set_scene(scene_data("three_spheres", w, h))
-        for pipelined in (False, True):
-            base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
-            fr = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1, pipelined=pipelined, _rehearse_single_rank=True)
-            for seed in range(5):
-                fr.params.seed = seed
-                fr.step()
-            fr.flush()
-            t = torch.tensor([2.5], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dist.barrier()
+        side = torch.cuda.Stream()
+        for pipelined, stream in ((False, None), (True, None), (False, side), (True, side)):   # default stream, then a side stream
+            with torch.cuda.stream(stream):
+                base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
+                fr = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1, pipelined=pipelined, _rehearse_single_rank=True)
+                for seed in range(5):
+                    fr.params.seed = seed
+                    fr.step()
+                fr.flush()
+                t = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dist.barrier()
             torch.cuda.synchronize()
             want = gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, seed=4))
-            assert_images_equal(fr.frame.cpu().numpy(), want, f"last of five frames, pipelined={pipelined}")
+            assert_images_equal(fr.frame.cpu().numpy(), want, f"last of five frames, pipelined={pipelined}, side stream={stream is not None}")
             assert float(t.item()) == 2.5
     finally:
         dist.destroy_process_group()
