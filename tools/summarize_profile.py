@@ -24,7 +24,7 @@ N_CU, SIMD_PER_CU = 256, 4
 
 def main() -> int:
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    needle = sys.argv[2] if len(sys.argv) > 2 else "render_pt_pool_kernel<256u, 112u, 6u, false, false, 3u>"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "render_pt_pool_kernel<256u, 112u, 6u, false, false, 3u, false>"
     kernel_id = sys.argv[3] if len(sys.argv) > 3 else "render_pt_pool_kernel<256,112,false,false>"
     src = ROOT / "gpurun_out" / f"prof_{tag}"
     dst = ROOT / "profiles"
