@@ -151,3 +151,12 @@ def test_rtiow_generator_is_deterministic():
     b, _ = m.scenes.rtiow_final()
     assert 470 <= len(a.spheres) <= 500 and len(a.spheres) == len(b.spheres) == len(a.materials)
     assert all(np.array_equal(x.center, y.center) for x, y in zip(a.spheres, b.spheres))
+
+
+def test_stream_argument_of_the_device_wrappers():
+    """None = the context's own stream (NULL in the C ABI); torch's default stream has handle 0, which must NOT
+    collapse into NULL -- it is passed as hipStreamLegacy (1); any other handle goes through unchanged."""
+    from weekend_raytracer_wgpu_amd.context import HIP_STREAM_LEGACY, _stream_arg
+    assert _stream_arg(None) is None
+    assert _stream_arg(0).value == HIP_STREAM_LEGACY == 1
+    assert _stream_arg(0x7f00dead0000).value == 0x7f00dead0000
