@@ -17,6 +17,13 @@
  *     consumer `Layer::register_texture` uploads (layer.rs:150-176, `to_rgba8`).
  *   - there is NO CPU fallback behind these symbols: without a HIP device every render call
  *     fails with MIRT_ERR_NO_DEVICE.
+ *   - threading: a context is used from one host thread at a time.  Its render calls may be queued
+ *     on DIFFERENT HIP streams and overlap on the device: every launch owns its work dispenser and
+ *     work counters, and carries the camera it was issued with.  Two exceptions, both about the
+ *     context's single accumulation buffer: mirt_ctx_accum_add calls must be ordered with respect to
+ *     each other by the caller (same stream, or events), and mirt_ctx_set_scene waits for the device.
+ *   - tuning knobs (MIRT_POOL_CONFIG, MIRT_GSS_*, ...) are read from the environment once, in
+ *     mirt_ctx_create; render calls never consult the environment.
  */
 #ifndef MIRT_H
 #define MIRT_H
@@ -244,7 +251,10 @@ void mirt_ctx_destroy(MirtContext* ctx);
  * `Layer::new` + `set_global_data` leave in `self`, layer.rs:49-148).  The scene stays
  * resident across render calls until replaced. */
 int mirt_ctx_set_scene(MirtContext* ctx, const MirtScene* scene);
-/* Replace only the camera (`Layer::update_camera`, layer.rs:188-193). */
+/* Replace only the camera (`Layer::update_camera`, layer.rs:188-193; `Raytracer::set_render_params`,
+ * mod.rs:353-388 — every interactive frame in the reference).  Host-side only: the camera travels by
+ * value with each launch, so this neither copies to the device nor synchronises; launches already
+ * queued keep their camera, the next render call uses the new one. */
 int mirt_ctx_set_camera(MirtContext* ctx, const MirtGpuCamera* camera);
 
 /* Render into HOST memory: kernel + D2H copy, blocking.  `out_rgba8` receives
@@ -278,7 +288,8 @@ int mirt_ctx_accum_add(MirtContext* ctx, const MirtParams* params, void* hip_str
 /* Samples per pixel accumulated since the last reset (`accumulated_samples_per_pixel`). */
 uint32_t mirt_ctx_accum_samples(const MirtContext* ctx);
 /* Resolve the buffer (mean over the accumulated samples, tone curves per params->flags) into
- * host memory, RGBA8; blocking. */
+ * host memory, RGBA8; blocking.  Ordered after every mirt_ctx_accum_add issued so far, whatever
+ * stream it was queued on (so is mirt_ctx_accum_read). */
 int mirt_ctx_accum_resolve(MirtContext* ctx, const MirtParams* params, uint8_t* out_rgba8, size_t out_len);
 /* Copy the raw sums to the host: pixels x 3 uint64 (the fp32-intermediate view used by tests). */
 int mirt_ctx_accum_read(MirtContext* ctx, uint64_t* out_sums, size_t out_len_u64);

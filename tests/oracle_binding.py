@@ -3,6 +3,7 @@ imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -25,9 +26,12 @@ def _cpu_has_fma() -> bool:
 
 def _load() -> C.CDLL:
     name = "libmirt_oracle.so" if _cpu_has_fma() else "libmirt_oracle_nofma.so"
+    target = []
+    if os.environ.get("MIRT_ORACLE_VARIANT") == "asan":      # tests/test_oracle_asan.py: ASan + UBSan build of the oracle
+        name, target = "libmirt_oracle_asan.so", ["asan"]
     path = BUILD / name
     if not path.exists():
-        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+        subprocess.run(["make", "-C", str(ROOT / "oracle")] + target, check=True, capture_output=True)
     lib = C.CDLL(str(path))
     P = C.POINTER
     fp = P(C.c_float)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import weekend_raytracer_wgpu_amd as m
-from helpers import GOLDEN, assert_images_equal, layer_scene_data
+from helpers import assert_images_equal, layer_scene_data
 
 ROOT = Path(__file__).resolve().parent.parent
 DEMO = ROOT / "weekend-raytracer-wgpu_amd" / "host" / "layer_demo"
@@ -18,7 +18,7 @@ def ppms(tmp_path_factory):
     d = tmp_path_factory.mktemp("ppm")
     out = {}
     for name in ("moon", "earthmap"):
-        a = np.load(GOLDEN / f"{name}_1024x512_rgb8.npz")["rgb8"]
+        a = np.load(m.asset_path(f"assets/{name}.jpeg"))["rgb8"]
         p = d / f"{name}.ppm"
         with open(p, "wb") as f:
             f.write(b"P6\n1024 512\n255\n")

@@ -27,8 +27,9 @@ def test_oracle_reproduces_golden(name, oracle):
 def test_texture_fixture_hashes():
     """sha256 of the decoded RGB8 texels (decoder-unpinned, see tools/make_texture_fixtures.py)."""
     import hashlib
-    earth = np.load(GOLDEN / "earthmap_1024x512_rgb8.npz")["rgb8"]
-    moon = np.load(GOLDEN / "moon_1024x512_rgb8.npz")["rgb8"]
+    import weekend_raytracer_wgpu_amd as m
+    earth = np.load(m.asset_path("assets/earthmap.jpeg"))["rgb8"]
+    moon = np.load(m.asset_path("assets/moon.jpeg"))["rgb8"]
     assert earth.shape == moon.shape == (512, 1024, 3)
     assert earth[0, 0].tolist() == [255, 255, 255]
     assert hashlib.sha256(earth.tobytes()).hexdigest().startswith("a8cdc92a168d554d")

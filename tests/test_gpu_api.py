@@ -233,3 +233,91 @@ def test_large_scene_with_one_material_per_sphere(gpu_ctx, oracle):
         with pytest.raises(m.MirtError) as e:
             gpu_ctx.render(bad)
         assert e.value.status_name == "MIRT_ERR_SCENE_TOO_LARGE"
+
+
+def test_set_camera_is_per_launch_and_needs_no_sync(gpu_ctx, oracle):
+    """`Layer::update_camera` / `set_render_params` change the camera every interactive frame (layer.rs:188-193,
+    mod.rs:353-388).  The camera travels by value with each launch: launches queued BEFORE a set_camera keep the
+    old camera, launches after it see the new one, and nothing synchronises in between."""
+    import torch
+    w, h, spp = 128, 72, 32
+    sd_a = scene_data("three_spheres", w, h)
+    cam_b = simple_camera(w, h, eye=(-3.0, 2.5, 6.0), direction=(0.4, -0.2, -1.0), vfov=40.0, aperture=0.2, focus=7.0)
+    sd_b = m.SceneData(cam_b, sd_a.spheres, sd_a.materials, sd_a.texels)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT)
+    gpu_ctx.set_scene(sd_a)
+    s = torch.cuda.Stream()
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    with torch.cuda.stream(s):
+        big = m.make_params(640, 360, 256, mode=m.MIRT_MODE_PT)            # keeps the stream busy while the host runs ahead
+        scratch = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+        gpu_ctx.render_device(big, scratch.data_ptr(), scratch.numel(), s.cuda_stream)
+        gpu_ctx.render_device(p, bufs[0].data_ptr(), bufs[0].numel(), s.cuda_stream)      # camera A
+        gpu_ctx.set_camera(cam_b)
+        gpu_ctx.render_device(p, bufs[1].data_ptr(), bufs[1].numel(), s.cuda_stream)      # camera B
+        gpu_ctx.set_camera(sd_a.camera)
+        gpu_ctx.render_device(p, bufs[2].data_ptr(), bufs[2].numel(), s.cuda_stream)      # camera A again
+        gpu_ctx.set_camera(cam_b)
+        gpu_ctx.render_device(p, bufs[3].data_ptr(), bufs[3].numel(), s.cuda_stream)
+    s.synchronize()
+    want_a, want_b = oracle.render(sd_a, p), oracle.render(sd_b, p)
+    assert not np.array_equal(want_a, want_b)
+    for i, want in enumerate((want_a, want_b, want_a, want_b)):
+        assert_images_equal(bufs[i].cpu().numpy(), want, f"launch {i}")
+    gpu_ctx.set_camera(sd_a.camera)
+
+
+def test_launches_of_one_context_overlap_on_two_streams(gpu_ctx, oracle):
+    """Every launch owns its strip dispenser and work counters: two renders of ONE context queued on different
+    streams may run at the same time without handing out a strip twice or skipping one."""
+    import torch
+    w, h = 320, 200
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    pa = m.make_params(w, h, 96, mode=m.MIRT_MODE_PT, seed=1)
+    pb = m.make_params(w, h, 64, mode=m.MIRT_MODE_PT, seed=2, flags=m.MIRT_FLAG_KERNEL_STRIP)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        a = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        b = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        gpu_ctx.render_device(pa, a.data_ptr(), a.numel(), s1.cuda_stream)
+        gpu_ctx.render_device(pb, b.data_ptr(), b.numel(), s2.cuda_stream)
+        outs.append((a, b))
+    torch.cuda.synchronize()
+    want_a, want_b = oracle.render(sd, pa), oracle.render(sd, pb)
+    for a, b in outs:
+        assert_images_equal(a.cpu().numpy(), want_a, "stream 1 (pool kernel)")
+        assert_images_equal(b.cpu().numpy(), want_b, "stream 2 (strip kernel)")
+
+
+def test_accum_resolve_waits_for_adds_on_a_caller_stream(gpu_ctx, oracle):
+    import torch
+    w, h = 160, 90
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, 16, mode=m.MIRT_MODE_PT)
+    s = torch.cuda.Stream()
+    gpu_ctx.accum_reset(p)
+    for _ in range(6):
+        gpu_ctx.accum_add(p, s.cuda_stream)
+    got = gpu_ctx.accum_resolve(p)                       # no explicit sync of `s` by the caller
+    sums = gpu_ctx.accum_read(p)
+    want = m.make_params(w, h, 96, mode=m.MIRT_MODE_PT)
+    assert_images_equal(got, oracle.render(sd, want), "6 x 16 spp on a side stream")
+    assert np.array_equal(sums, oracle.render_pt_sums(sd, want))
+
+
+def test_set_scene_is_failure_atomic(gpu_ctx):
+    """A set_scene that fails (here: rejected up front) or half-fails leaves the context without a scene
+    rather than with stale tables: the next render must answer MIRT_ERR_NO_SCENE or render the OLD scene whole."""
+    w, h = 32, 24
+    sd = layer_scene_data(w, h)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, 2)
+    want = gpu_ctx.render(p)
+    cam = simple_camera(8, 8)
+    mats, tex = m.flatten_materials([m.Material.Dielectric(1.5)] * 3)
+    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 4000
+    assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
+    assert_images_equal(gpu_ctx.render(p), want, "old scene intact after a rejected set_scene")

@@ -2,10 +2,10 @@
 """Decode the reference's two albedo maps into raw RGB8 texel fixtures.
 
 Runs ONLY in the authoring container (it reads /root/reference/assets); the outputs are
-committed under tests/golden/ so that nothing at test/bench time needs the reference tree.
+committed as package data (weekend-raytracer-wgpu_amd/assets/) so that nothing at test/bench time needs the reference tree.
 
-    assets/earthmap.jpeg  (1024x512 baseline JPEG)    -> tests/golden/earthmap_1024x512_rgb8.npz
-    assets/moon.jpeg      (1024x512 progressive JPEG) -> tests/golden/moon_1024x512_rgb8.npz
+    assets/earthmap.jpeg  (1024x512 baseline JPEG)    -> weekend-raytracer-wgpu_amd/assets/earthmap_1024x512_rgb8.npz
+    assets/moon.jpeg      (1024x512 progressive JPEG) -> weekend-raytracer-wgpu_amd/assets/moon_1024x512_rgb8.npz
 
 Image credits (reference README.md:123-132): the earth and moon maps ship with
 linuxing3/weekend-raytracer-wgpu (MIT), which credits NASA / Solar System Scope textures.
@@ -26,7 +26,7 @@ import numpy as np
 from PIL import Image
 
 REF = Path("/root/reference/assets")
-OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+OUT = Path(__file__).resolve().parent.parent / "weekend-raytracer-wgpu_amd" / "assets"
 
 
 def main() -> int:

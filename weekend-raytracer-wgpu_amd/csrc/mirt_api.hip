@@ -93,7 +93,7 @@ V3 sub3(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
 
 // Build the uniform grid of mirt_kernels.h over the spheres of a many-sphere scene.  Returns an empty
 // blob when a grid would not help (few spheres, or nothing small enough to bin).
-std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n)
+std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double cell_factor_knob)
 {
     std::vector<unsigned char> blob;
     if (n < mirt::kGridMinSpheres || n > 65535u) return blob;
@@ -116,8 +116,7 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n)
         }
     }
     if (small.size() < mirt::kGridMinSpheres / 2 || big.size() > 64) return blob;
-    double cell_factor = 4.0;                                    // cell = 4 median radii: a binned sphere spans at most 3 cells per axis
-    if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) cell_factor = v; }   // tuning knob
+    const double cell_factor = cell_factor_knob > 0.0 ? cell_factor_knob : 4.0;   // cell = 4 median radii: a binned sphere spans at most 3 cells per axis
     double cell = cell_factor * r_med;
     uint32_t dims[3];
     for (;;) {
@@ -172,6 +171,34 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n)
     return blob;
 }
 
+// Tuning / experiment knobs.  They are read from the environment ONCE, when a context is created
+// (mirt_ctx_create), never inside a render call: a shipped library must not change its schedule
+// because a variable appeared mid-run, and getenv has no place in a sub-millisecond launch path.
+struct Tuning {
+    int      pool_config = -1;        // MIRT_POOL_CONFIG: geometry of the path pool (index into kPoolConfigs)
+    int      pool_grid = -1;          // MIRT_POOL_GRID=0: never take the pool kernel's grid build
+    bool     fixed_strips = false;    // MIRT_STRIP_MODE=16: fixed 16-pixel strips (no guided self-scheduling)
+    uint32_t gss_min_width = 0;       // MIRT_GSS_MINW: narrowest strip of the guided schedule
+    double   gss_keep = 0.0;          // MIRT_GSS_KEEP: strips per resident wave kept for the narrower levels
+    int      by_pixel = -1;           // MIRT_BY_PIXEL=0/1: force lane = sample / lane = pixel in the strip kernel
+    uint32_t pool_blocks_per_cu = 0;  // MIRT_POOL_BLOCKS_PER_CU: fewer resident pool blocks (occupancy experiments)
+    double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
+};
+
+Tuning read_tuning()
+{
+    Tuning t;
+    if (const char* e = std::getenv("MIRT_POOL_CONFIG")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) t.pool_config = (int)v; }
+    if (const char* e = std::getenv("MIRT_POOL_GRID")) t.pool_grid = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_STRIP_MODE")) t.fixed_strips = e[0] == '1';
+    if (const char* e = std::getenv("MIRT_GSS_MINW")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v <= 16) t.gss_min_width = v; }
+    if (const char* e = std::getenv("MIRT_GSS_KEEP")) { const double v = std::atof(e); if (v > 0.0 && v < 64.0) t.gss_keep = v; }
+    if (const char* e = std::getenv("MIRT_BY_PIXEL")) t.by_pixel = (e[0] == '1') ? 1 : 0;
+    if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
+    if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
+    return t;
+}
+
 template <typename T>
 int ensure_capacity(T** ptr, size_t* cap, size_t need)
 {
@@ -209,7 +236,7 @@ struct MirtContext {
     uint32_t queue_routine[5] = {0, 1, 2, 3, 4};   // dense numbering of the routines present (pool kernel queues)
     int      pt_scene_status = MIRT_OK;
     int      parity_scene_status = MIRT_OK;
-    MirtGpuCamera*        d_cam = nullptr;
+    MirtGpuCamera         cam{};          // host copy; travels by value with every launch (RenderArgs.cam)
     mirt::PreparedSphere* d_spheres = nullptr;
     MirtMaterial*         d_mats = nullptr;
     mirt::PreparedMaterial* d_pmats = nullptr;
@@ -222,9 +249,15 @@ struct MirtContext {
     MirtSkyState*         d_sky = nullptr;
     size_t cap_spheres = 0, cap_mats = 0, cap_texels = 0;
 
-    // per-launch state
-    unsigned long long* d_counters = nullptr;
-    uint32_t*           d_work_counter = nullptr;
+    Tuning tuning;
+
+    // per-launch state: every launch owns the dispenser word and the counter block of its event slot, so
+    // launches of one context that overlap on different streams cannot disturb each other
+    unsigned long long* d_counters = nullptr;      // [kEventPool][kNumCounters]
+    uint32_t*           d_work_counter = nullptr;  // [kEventPool]
+    size_t              last_slot = 0;             // event slot of the last launch (its counters feed MirtStats)
+    hipEvent_t          ev_accum = nullptr;        // end of the last launch that adds into d_accum
+    bool                accum_pending = false;
     uint32_t*           d_out = nullptr;     // scratch framebuffer for host-output renders
     size_t              cap_out = 0;
     unsigned long long* d_accum = nullptr;   // progressive accumulation: [pixels][3] exact sums
@@ -370,10 +403,10 @@ int mirt_ctx_create(int device, MirtContext** out)
         if (a) c->ev_begin.push_back(a);
         if (b) c->ev_end.push_back(b);
     }
-    if (e == hipSuccess) e = hipMalloc(&c->d_cam, sizeof(MirtGpuCamera));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
-    if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters);
-    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters * kEventPool);
+    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool);
     if (e != hipSuccess) {
         const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         mirt_ctx_destroy(c);
@@ -382,6 +415,7 @@ int mirt_ctx_create(int device, MirtContext** out)
     c->cu_count = prop.multiProcessorCount;
     c->lds_per_block = prop.sharedMemPerBlock;            // 160 KiB on gfx950
     c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
+    c->tuning = read_tuning();
     *out = c;
     return MIRT_OK;
 }
@@ -391,10 +425,11 @@ void mirt_ctx_destroy(MirtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_cam); (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_texels);
+    (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
+    if (c->ev_accum) (void)hipEventDestroy(c->ev_accum);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -408,13 +443,17 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
     // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
     const bool fits_flat = mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
-    const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres);
+    const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell);
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
                            mirt::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;
     if (!fits_flat && !fits_grid)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
                     s->n_materials, mirt::kMaxLdsBytes);
     HIP_TRY(hipSetDevice(c->device));
+    // Failure-atomic: from here until the last copy has succeeded the context holds NO scene, so an allocation or
+    // copy that fails half-way leaves render calls answering MIRT_ERR_NO_SCENE instead of launching on freed or
+    // half-written tables.
+    c->have_scene = false;
     c->fits_flat = fits_flat;
 
     // mode-specific validity is decided here once and reported by the render call that needs it
@@ -487,7 +526,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if ((rc = ensure_capacity(&c->d_mats, &c->cap_mats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_texels, &c->cap_texels, (size_t)s->n_texels * 3)) != MIRT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());      // renders may be in flight on caller streams (mirt_ctx_render_device)
-    HIP_TRY(hipMemcpy(c->d_cam, s->camera, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
+    c->cam = *s->camera;
     if (s->n_spheres) HIP_TRY(hipMemcpy(c->d_spheres, prep.data(), prep.size() * sizeof(mirt::PreparedSphere), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_pmats, pmats.data(), pmats.size() * sizeof(mirt::PreparedMaterial), hipMemcpyHostToDevice));
@@ -512,9 +551,10 @@ int mirt_ctx_set_camera(MirtContext* c, const MirtGpuCamera* cam)
 {
     if (!c || !cam) return fail(MIRT_ERR_NULL_POINTER, "ctx/camera is null");
     if (!c->have_scene) return fail(MIRT_ERR_NO_SCENE, "set_scene has not been called");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());      // renders may be in flight on caller streams (mirt_ctx_render_device)
-    HIP_TRY(hipMemcpy(c->d_cam, cam, sizeof(MirtGpuCamera), hipMemcpyHostToDevice));
+    // No device work at all: the camera is a kernel argument of every launch (RenderArgs.cam).  Launches already
+    // queued keep the camera they were issued with; the next render call uses this one.  The reference updates the
+    // camera every interactive frame (layer.rs:188-193, mod.rs:353-388), so this must cost nothing.
+    c->cam = *cam;
     return MIRT_OK;
 }
 
@@ -571,11 +611,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const size_t scene_lds = mirt::scene_lds_bytes(c->n_spheres, c->n_mats, pt, hosek);
     // kernel choice (path-traced mode): the pooled kernel needs enough samples per tile to keep
     // its path pool full, 8-bit bounce counters and room for the pool beside the scene in LDS
-    uint32_t pool_cfg = mirt::kDefaultPoolConfig;
-    if (const char* e = std::getenv("MIRT_POOL_CONFIG")) {          // tuning knob: geometry of the path pool
-        const long v = std::strtol(e, nullptr, 10);
-        if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) pool_cfg = (uint32_t)v;
-    }
+    const Tuning& tune = c->tuning;
+    const uint32_t pool_cfg = tune.pool_config >= 0 ? (uint32_t)tune.pool_config : mirt::kDefaultPoolConfig;
     const uint32_t pool_nq = mirt::pool_scatter_queues(c->n_shading_routines, count);
     const mirt::PoolConfig pc = mirt::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when paths diverge over >= 2 scatter routines,
@@ -598,13 +635,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
                      lds_pool_grid_block <= (size_t)c->lds_per_block && !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
                       (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 12));
-    if (const char* e = std::getenv("MIRT_POOL_GRID")) { if (e[0] == '0') pool_grid = false; }   // experiment knob
+    if (tune.pool_grid == 0) pool_grid = false;
     if (pool_grid) pool = true;
     const uint32_t resident_pool_waves = pool_grid ? pool_grid_waves_per_cu : pool_waves_per_cu;
 
     mirt::RenderArgs a{};
-    a.cam = c->d_cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
-    a.out = d_out; a.counters = c->d_counters; a.work_counter = c->d_work_counter; a.accum = d_accum;
+    a.cam = c->cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
+    a.out = d_out; a.counters = c->d_counters + ev * mirt::kNumCounters; a.work_counter = c->d_work_counter + ev; a.accum = d_accum;
     a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
     a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
@@ -623,14 +660,12 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // an N-way partition vs 1/N of the whole frame): fixed 16-pixel strips 95 / 83 / 67 % at N = 2 / 4 / 8,
         // this schedule 99 / 95 / 90 %; strips narrower than 4 pixels lose more to pool fill/drain than they
         // gain.  Narrow strips also need width x spp >= 512 work items to keep a wave's pool busy.
-        const char* strip_mode = std::getenv("MIRT_STRIP_MODE");   // experiment knob: "16" = fixed 16-pixel strips
         const uint64_t waves = (uint64_t)c->cu_count * (resident_pool_waves < 32u ? resident_pool_waves : 32u);   // resident waves (LDS-bound)
         uint32_t min_width = 4;
         while (min_width < mirt::kStripPixels && (uint64_t)min_width * p->spp < 512u) min_width *= 2;
-        if (strip_mode && strip_mode[0] == '1') min_width = mirt::kStripPixels;
-        double keep_factor = 4.0;
-        if (const char* e = std::getenv("MIRT_GSS_MINW")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v <= 16) min_width = v; }
-        if (const char* e = std::getenv("MIRT_GSS_KEEP")) { const double v = std::atof(e); if (v > 0.0 && v < 64.0) keep_factor = v; }
+        if (tune.fixed_strips) min_width = mirt::kStripPixels;
+        if (tune.gss_min_width) min_width = tune.gss_min_width;
+        const double keep_factor = tune.gss_keep > 0.0 ? tune.gss_keep : 4.0;
         uint64_t pix = 0, unit = 0;
         for (uint32_t l = 0; l < mirt::kStripLevels; ++l) {
             const uint32_t width = mirt::kStripPixels >> l;
@@ -663,7 +698,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     // few samples per pixel (the reference's interactive loop adds 2 per frame): lane = pixel instead of lane = sample
     bool by_pixel = pt && !pool && !count && p->spp < mirt::kByPixelMaxSpp;
-    if (const char* e = std::getenv("MIRT_BY_PIXEL")) by_pixel = pt && !pool && !count && e[0] == '1';   // experiment knob
+    if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
     a.static_units = 0;
     if (by_pixel) {
         a.n_units = (uint32_t)((npix + 63u) / 64u);
@@ -675,7 +710,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
         const uint32_t by_waves = 32u / (pc.threads / 64u);   // upper bound; LDS decides (6 blocks of 4 waves with 112-slot pools)
         if (per_cu > by_waves) per_cu = by_waves;
-        if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // tuning knob: fewer resident waves
+        if (tune.pool_blocks_per_cu >= 1 && tune.pool_blocks_per_cu < per_cu) per_cu = tune.pool_blocks_per_cu;
         if (per_cu == 0u) per_cu = 1u;
         blocks = (uint32_t)c->cu_count * per_cu;
         const uint32_t units_per_block = pc.threads / 64u;
@@ -691,14 +726,19 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
     const uint32_t launched_waves = blocks * ((pool ? pc.threads : mirt::kBlockThreads) / 64u);
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_work_counter, (int)launched_waves, 1, stream));
-    if (count) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
+    if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
     else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
     else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
+    if (d_accum) {                                   // resolve/read must see these sums whatever stream they were added on
+        HIP_TRY(hipEventRecord(c->ev_accum, stream));
+        c->accum_pending = true;
+    }
     c->ev_used = ev + 1;
+    c->last_slot = ev;
     c->stats_counted = count;
     c->stats = MirtStats{};
     c->stats.samples = npix * p->spp;
@@ -755,7 +795,7 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
     c->launches_folded = 0;
     if (had_launch && c->stats_counted) {
         unsigned long long h[mirt::kNumCounters];
-        HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h, c->d_counters + c->last_slot * mirt::kNumCounters, sizeof h, hipMemcpyDeviceToHost));
         c->stats.rays = h[mirt::kCntRays];
         c->stats.sphere_tests = h[mirt::kCntTests];
         c->stats.roots = h[mirt::kCntRoots];
@@ -781,6 +821,7 @@ int mirt_ctx_accum_reset(MirtContext* c, const MirtParams* p)
     if (p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "progressive accumulation exists in path-traced mode only");
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t npix = (uint64_t)out_rows(p) * p->width;
+    if (c->accum_pending) { HIP_TRY(hipEventSynchronize(c->ev_accum)); c->accum_pending = false; }   // no add may still be running
     if ((rc = ensure_capacity(&c->d_accum, &c->cap_accum, (size_t)npix * 3)) != MIRT_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->d_accum, 0, (size_t)npix * 3 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -817,6 +858,7 @@ int mirt_ctx_accum_resolve(MirtContext* c, const MirtParams* p, uint8_t* out, si
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = ensure_capacity(&c->d_out, &c->cap_out, (size_t)c->accum_pixels)) != MIRT_OK) return rc;
+    if (c->accum_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_accum, 0));   // adds may sit on a caller stream
     HIP_TRY(mirt::launch_resolve(c->d_accum, c->d_out, c->accum_pixels, c->accum_samples, p->flags, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)c->accum_pixels * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -829,6 +871,7 @@ int mirt_ctx_accum_read(MirtContext* c, uint64_t* out_sums, size_t out_len_u64)
     if (!c->d_accum) return fail(MIRT_ERR_NO_SCENE, "nothing accumulated yet");
     if (out_len_u64 < c->accum_pixels * 3) return fail(MIRT_ERR_OUT_BUFFER, "output buffer too small");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->accum_pending) HIP_TRY(hipEventSynchronize(c->ev_accum));                 // adds may sit on a caller stream
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_sums, c->d_accum, (size_t)c->accum_pixels * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MIRT_OK;
@@ -838,6 +881,7 @@ int mirt_ctx_selftest_math(MirtContext* c, uint64_t out[2])
 {
     if (!c || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = mirt_ctx_synchronize(c); if (rc != MIRT_OK) return rc; }    // borrows counter block 0
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
     HIP_TRY(mirt::launch_selftest_math(c->d_counters, c->stream));
     unsigned long long h[2] = { 0, 0 };

@@ -74,17 +74,21 @@ enum CounterSlot : uint32_t {
 };
 
 struct RenderArgs {
-    const MirtGpuCamera*    cam;
+    // The camera travels BY VALUE with every launch (96 B of kernel arguments, staged into LDS from the kernarg
+    // segment): `Layer::update_camera` / `set_render_params` (layer.rs:188-193, mod.rs:353-388) change it every
+    // interactive frame, and this way mirt_ctx_set_camera needs no device copy and no synchronisation, and a
+    // launch already queued keeps the camera it was issued with.  MUST stay the first member (stage_scene).
+    MirtGpuCamera           cam;
     const PreparedSphere*   spheres;
     const MirtMaterial*     mats;          // reference layout (parity kernel)
     const PreparedMaterial* pmats;         // derived layout (path-traced kernels)
     const float*            texels;
     const MirtSkyState*     sky;
     uint32_t*               out;           // compact RGBA8, one u32 per pixel
-    unsigned long long*     counters;      // [kNumCounters], COUNT builds only
+    unsigned long long*     counters;      // [kNumCounters] of THIS launch (one block per event slot), COUNT builds only
     const unsigned char*    grid;          // nullable: GridHeader + lists (strip kernel, GRID build)
     uint32_t                grid_bytes;
-    uint32_t*               work_counter;  // dynamic work dispenser, zeroed before every launch
+    uint32_t*               work_counter;  // dynamic work dispenser: THIS launch's own word (one per event slot), preset before the launch
     unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;
     uint32_t n_spheres, n_mats;

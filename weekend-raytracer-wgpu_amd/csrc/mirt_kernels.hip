@@ -46,14 +46,19 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     const uint32_t n_mat = MATS_IN_LDS ? A.n_mats * kMatQuads : 0u;
     const uint32_t n_sky = hosek ? sizeof(MirtSkyState) / 16 : 0;
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    const uint4* src_cam = reinterpret_cast<const uint4*>(A.cam);
+    // the camera is the first kernel argument, by value: read it from the kernarg segment (constant address
+    // space, vector loads) so that thread i copies quad i without a private copy of the struct
+    static_assert(offsetof(RenderArgs, cam) == 0, "camera must be the first kernel argument");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(4))) const u32x4 kernarg_quad;
+    kernarg_quad* src_cam = (kernarg_quad*)__builtin_amdgcn_kernarg_segment_ptr();
     const uint4* src_sph = reinterpret_cast<const uint4*>(A.spheres);
     const uint4* src_mat = PT ? reinterpret_cast<const uint4*>(A.pmats) : reinterpret_cast<const uint4*>(A.mats);
     const uint4* src_sky = reinterpret_cast<const uint4*>(A.sky);
     const uint32_t total = n_cam + n_sph + n_mat + n_sky;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
         uint4 v;
-        if (i < n_cam) v = src_cam[i];
+        if (i < n_cam) { const u32x4 q = src_cam[i]; v = make_uint4(q.x, q.y, q.z, q.w); }
         else if (i < n_cam + n_sph) v = src_sph[i - n_cam];
         else if (i < n_cam + n_sph + n_mat) v = src_mat[i - n_cam - n_sph];
         else v = src_sky[i - n_cam - n_sph - n_mat];

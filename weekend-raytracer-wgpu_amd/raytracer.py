@@ -347,12 +347,12 @@ _ASSET_FIXTURES = {
 
 
 def asset_path(name: str) -> str:
-    """Resolve the reference's hard-coded asset paths (layer.rs:97,108) to the decoded fixtures that
-    ship with this repo (tests/golden/), unless the file itself exists relative to the CWD."""
+    """Resolve the reference's hard-coded asset paths (layer.rs:97,108) to the decoded texel tables that
+    ship as package data (weekend-raytracer-wgpu_amd/assets/, written by tools/make_texture_fixtures.py),
+    unless the file itself exists relative to the CWD."""
     if Path(name).exists():
         return name
-    fixture = Path(__file__).resolve().parent.parent / "tests" / "golden" / _ASSET_FIXTURES.get(name, name)
-    return str(fixture)
+    return str(Path(__file__).resolve().parent / "assets" / _ASSET_FIXTURES.get(name, name))
 
 
 # ------------------------------------------------------------------------------------------------
