@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MIRT_VERSION_MAJOR 0
-#define MIRT_VERSION_MINOR 1
+#define MIRT_VERSION_MINOR 2
 #define MIRT_VERSION_PATCH 0
 
 /* ------------------------------------------------------------------------------------------
@@ -129,7 +129,7 @@ enum {
     MIRT_MODE_PT = 1
 };
 
-/* Flags (MIRT_MODE_PT only; ignored in parity mode). */
+/* Flags (MIRT_MODE_PT only, except MIRT_FLAG_COUNT_WORK which both modes honour). */
 enum {
     MIRT_FLAG_SKY_HOSEK      = 1u << 0, /* sky = Hosek-Wilkie blob (wgsl:154-166,316-343); default: RTIOW gradient */
     MIRT_FLAG_NO_TONEMAP     = 1u << 1, /* skip uncharted2 (wgsl:83-103) */
@@ -139,7 +139,11 @@ enum {
      * pooled kernel (paths queued by material in LDS) when spp >= 48, else the strip kernel. */
     MIRT_FLAG_KERNEL_STRIP   = 1u << 4, /* force the strip kernel (wave = 64 samples of one pixel) */
     MIRT_FLAG_KERNEL_POOL    = 1u << 5, /* force the pooled kernel */
-    MIRT_FLAG_NO_GRID        = 1u << 6  /* many-sphere scenes: scan the flat sphere list instead of the uniform grid */
+    MIRT_FLAG_NO_GRID        = 1u << 6, /* many-sphere scenes: scan the flat sphere list instead of the uniform grid */
+    /* With MIRT_FLAG_COUNT_WORK on a many-sphere scene: count the work of the grid build that renders such
+     * scenes in production (sphere_tests = tests a lane really performs, grid_cells) instead of falling back to
+     * the reference's flat scan, whose counters are the oracle's. */
+    MIRT_FLAG_COUNT_GRID     = 1u << 7
 };
 
 /* What one render call computes.  The image is `width x height`; this call renders the rows
@@ -165,7 +169,9 @@ typedef struct MirtParams {
 } MirtParams;
 
 /* Work counters of the last render on a context (rocprof-independent).  The ray/test/scatter
- * counters are filled only when MIRT_FLAG_COUNT_WORK was set. */
+ * counters are filled only when MIRT_FLAG_COUNT_WORK was set.  Parity mode counts what the reference's
+ * sequential sample loop executes (it returns at the first terminating sample, layer.rs:333-374):
+ * lane_iterations = samples executed, scatter[1] = scatter_metal calls. */
 typedef struct MirtStats {
     double   kernel_ms;        /* hipEvent time of the render kernel of the LAST render call */
     double   kernel_ms_total;  /* summed over every render call since the previous mirt_ctx_get_stats */
@@ -179,6 +185,8 @@ typedef struct MirtStats {
     uint64_t sky_misses;       /* rays that left the scene */
     uint64_t lane_iterations;  /* PT: active lanes summed over bounce-loop iterations */
     uint64_t wave_iterations;  /* PT: bounce-loop iterations summed over waves (x64 = lane slots) */
+    uint64_t grid_cells;       /* MIRT_FLAG_COUNT_GRID: grid cells visited, summed over lanes */
+    uint64_t grid_wave_cells;  /* MIRT_FLAG_COUNT_GRID: cell-loop iterations summed over waves (x64 = lane slots) */
 } MirtStats;
 
 typedef enum MirtStatus {

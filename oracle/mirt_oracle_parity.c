@@ -232,6 +232,7 @@ static void ray_color_per_pixel(const pctx_t* P, uint32_t x, uint32_t y, uint8_t
     v3 pixel_color = V(0, 0, 0);
     for (uint32_t s = 0; s < P->spp; ++s) {
         float uu = u + 0.0f, vv = v + 0.0f;            /* Q1 */
+        P->st->lane_iterations++;                      /* samples the sequential loop executes before it returns */
         ray_t ray = make_ray(P->cam, uu, vv);
         isect_t rec = isect_new();                     /* Box::into_raw(Box::new(Intersection::new())) */
         if (ray_hit_world_raw(P, &ray, 0.001f, FLT_MAX, &rec)) {

@@ -101,6 +101,7 @@ pub const MIRT_FLAG_COUNT_WORK: u32 = 1 << 3;
 pub const MIRT_FLAG_KERNEL_STRIP: u32 = 1 << 4;
 pub const MIRT_FLAG_KERNEL_POOL: u32 = 1 << 5;
 pub const MIRT_FLAG_NO_GRID: u32 = 1 << 6;
+pub const MIRT_FLAG_COUNT_GRID: u32 = 1 << 7;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -135,6 +136,8 @@ pub struct MirtStats {
     pub sky_misses: u64,
     pub lane_iterations: u64,
     pub wave_iterations: u64,
+    pub grid_cells: u64,
+    pub grid_wave_cells: u64,
 }
 
 #[repr(C)]

@@ -59,7 +59,7 @@ def test_status_strings_match_header_enum():
 
 
 def test_version():
-    assert m.lib().mirt_version() == (0 << 16) | (1 << 8) | 0
+    assert m.lib().mirt_version() == (0 << 16) | (2 << 8) | 0
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

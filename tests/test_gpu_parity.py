@@ -164,3 +164,26 @@ def test_full_size_parity_properties(gpu_ctx, oracle):
         img = gpu_ctx.render(m.multi_gpu.part_params(base, r, 8, 4))
         parts[r, :img.shape[0]] = img
     assert_images_equal(m.multi_gpu.assemble_host(parts, base, 8, 4), img21, "8-way tiles 1080p")
+
+
+COUNTED = ("rays", "sphere_tests", "roots", "hits", "lane_iterations")
+
+
+@pytest.mark.parametrize("spp", [2, 21, 100])
+def test_parity_work_counters_match_oracle(gpu_ctx, oracle, spp):
+    """MIRT_FLAG_COUNT_WORK in parity mode counts the work of the reference's SEQUENTIAL sample loop (it returns at
+    the first terminating sample) although the kernel computes 64 samples of a pixel at once: rays, sphere tests,
+    roots, hit records, scatter_metal calls and samples executed must equal the oracle's tallies exactly."""
+    w, h = 200, 150
+    sd = layer_scene_data(w, h)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, spp, flags=m.MIRT_FLAG_COUNT_WORK)
+    got_img = gpu_ctx.render(p)
+    got = gpu_ctx.stats()
+    want_img = oracle.render(sd, p, n_threads=4)
+    want = oracle.stats()
+    assert_images_equal(got_img, want_img, "counting build image")
+    for k in COUNTED:
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert got["scatter"][1] == want["scatter"][1] > 0
+    assert got["samples"] == w * h * spp

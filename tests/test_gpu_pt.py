@@ -385,3 +385,26 @@ def test_grid_with_rays_parallel_to_axes(gpu_ctx, oracle):
     sd = m.SceneData(cam, spheres, gm, tex)
     p = m.make_params(65, 3, 8, mode=m.MIRT_MODE_PT, num_bounces=4, flags=LINEAR)
     assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), "axis-parallel rays")
+
+
+@pytest.mark.parametrize("kernel", [m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
+def test_grid_counting_build(gpu_ctx, oracle, kernel):
+    """MIRT_FLAG_COUNT_WORK | MIRT_FLAG_COUNT_GRID counts the grid build that renders many-sphere scenes in
+    production: same image, same rays / hits / scatters / sky misses as the reference's flat scan (the path is
+    identical), but FEWER sphere tests, plus the cells it walked."""
+    w, h, spp = 96, 54, 64
+    sd = scene_data("rtiow_final", w, h)
+    gpu_ctx.set_scene(sd)
+    flat = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, flags=kernel | m.MIRT_FLAG_COUNT_WORK)
+    grid = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, flags=kernel | m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)
+    img_flat = gpu_ctx.render(flat)
+    st_flat = gpu_ctx.stats()
+    img_grid = gpu_ctx.render(grid)
+    st_grid = gpu_ctx.stats()
+    assert_images_equal(img_grid, img_flat, "grid counting build image")
+    assert_images_equal(img_flat, oracle.render(sd, flat), "vs oracle")
+    for k in ("rays", "hits", "sky_misses", "scatter"):
+        assert st_grid[k] == st_flat[k], k
+    assert st_flat["grid_cells"] == 0 and st_flat["sphere_tests"] == st_flat["rays"] * len(sd.spheres)
+    assert 0 < st_grid["sphere_tests"] < st_flat["sphere_tests"] // 10
+    assert st_grid["grid_cells"] > 0 and st_grid["grid_cells"] <= 64 * st_grid["grid_wave_cells"]

@@ -604,7 +604,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const size_t ev = c->ev_used;
     const uint32_t rows = out_rows(p);
     const uint64_t npix = (uint64_t)rows * p->width;
-    const bool count = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_COUNT_WORK);
+    const bool count = (p->flags & MIRT_FLAG_COUNT_WORK) != 0;
     const bool hosek = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_SKY_HOSEK);
 
     const bool pt = p->mode == MIRT_MODE_PT;
@@ -628,7 +628,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
     const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
-    const bool grid_ok = pt && !count && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
+    // counting launches keep the reference's flat scan (their counters are then the oracle's) unless
+    // MIRT_FLAG_COUNT_GRID asks for the work of the grid build that renders the scene in production
+    const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
     const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pc.lds_bytes;
     const uint32_t pool_grid_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_grid_block ? lds_pool_grid_block : 1)) * (pc.threads / 64u);
     bool pool_grid = grid_ok && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
@@ -729,7 +731,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
-    if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, stream));
+    if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, count, stream));
     else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
     else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
@@ -805,6 +807,8 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.sky_misses = h[mirt::kCntSky];
         c->stats.lane_iterations = h[mirt::kCntLaneIters];
         c->stats.wave_iterations = h[mirt::kCntWaveIters];
+        c->stats.grid_cells = h[mirt::kCntCells];
+        c->stats.grid_wave_cells = h[mirt::kCntWaveCells];
 #ifdef MIRT_STAMP
         c->stats.scatter[0] = h[12]; c->stats.scatter[1] = h[13]; c->stats.scatter[2] = h[14]; c->stats.sky_misses = h[15];
 #endif

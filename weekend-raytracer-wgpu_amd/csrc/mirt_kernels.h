@@ -70,7 +70,8 @@ constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cann
 enum CounterSlot : uint32_t {
     kCntRays = 0, kCntTests, kCntRoots, kCntHits,
     kCntScatter0, kCntScatter1, kCntScatter2, kCntScatter3, kCntScatter4,
-    kCntSky, kCntLaneIters, kCntWaveIters
+    kCntSky, kCntLaneIters, kCntWaveIters,
+    kCntCells, kCntWaveCells            // grid builds: cells visited by lanes / cell-loop iterations of waves
 };
 
 struct RenderArgs {
@@ -114,7 +115,7 @@ struct DeinterleaveArgs {
 };
 
 // launchers (mirt_kernels.hip)
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream);
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();

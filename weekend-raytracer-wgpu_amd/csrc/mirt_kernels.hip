@@ -144,6 +144,24 @@ MIRT_DEV unsigned long long wave_sum_u64(unsigned long long v)
 
 MIRT_DEV uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16) | 0xff000000u; }
 
+// per-lane work counters of the counting builds (MIRT_FLAG_COUNT_WORK); compiled away otherwise
+template <bool COUNT>
+struct Work {
+    uint32_t c[kNumCounters];
+    MIRT_DEV void clear() { if constexpr (COUNT) { for (uint32_t i = 0; i < kNumCounters; ++i) c[i] = 0; } }
+    MIRT_DEV void add(uint32_t slot, uint32_t n = 1) { if constexpr (COUNT) c[slot] += n; }
+    MIRT_DEV void flush(unsigned long long* g, uint32_t lane)
+    {
+        if constexpr (COUNT) {
+            for (uint32_t i = 0; i < kNumCounters; ++i) {
+                const unsigned long long t = wave_sum_u64(c[i]);
+                if (lane == 0 && t) atomicAdd(&g[i], t);
+                c[i] = 0;
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // render_parity — layer.rs semantics
 // ------------------------------------------------------------------------------------------
@@ -155,9 +173,13 @@ struct PHit { f3 p, n; };
 // and `update_ray_hit_info` / `set_face_normal` (mod.rs:1217-1243, 1095-1110).
 // Returns the LAST sphere in list order with a root in [tmin, tmax]: `closest_hit` is reset to
 // `old_hit` = rec.t, which nobody ever writes (it stays f32::MAX).
+struct PCount { uint32_t tests, roots, hits; };     // what ONE ray_hit_world_raw call costs the reference
+
+template <bool COUNT>
 MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay& ray, float tmin, float tmax,
-                               const float rec_t, PHit& rec)
+                               const float rec_t, PHit& rec, PCount& pc)
 {
+    if constexpr (COUNT) { pc.tests = n_spheres; pc.roots = 0; pc.hits = 0; }
     bool hit_anything = false;
     float closest_hit = tmax;
     const float old_hit = rec_t;
@@ -172,10 +194,13 @@ MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay
         if (disc < 0.0f) continue;                       // `< 0.0` rejects: disc == 0 and NaN go on
         const float sq = sqrt_(disc);
         float t = (-half_b - sq) / a;
+        if constexpr (COUNT) pc.roots += 1;
         if (t < tmin || closest_hit < t) {
             t = (-half_b + sq) / a;
+            if constexpr (COUNT) pc.roots += 1;
             if (t < tmin || closest_hit < t) continue;
         }
+        if constexpr (COUNT) pc.hits += 1;
         // update_ray_hit_info: `if t < 0.0 { return false }` cannot trigger (t >= tmin > 0)
         const f3 p = ray.o + mk(ray.d.x * t, ray.d.y * t, ray.d.z * t);
         const f3 n = sp.inv_r * (p - c);
@@ -188,6 +213,10 @@ MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay
     return hit_anything;
 }
 
+// COUNT = true additionally tallies the work the REFERENCE's sequential sample loop performs (it returns at
+// the first terminating sample): only the samples up to and including that one are counted, although all 64
+// lanes of a batch compute theirs.  Same meaning as the oracle's counters (tests/test_gpu_parity.py).
+template <bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -201,6 +230,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
     const f3 hor = mk(S.cam[4], S.cam[5], S.cam[6]);
     const f3 ver = mk(S.cam[8], S.cam[9], S.cam[10]);
     const f3 llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    Work<COUNT> work;
+    work.clear();
 
     for (uint32_t strip = first_unit(); strip < A.n_units; strip = next_unit(A, lane)) {
         const uint32_t base = strip * kStripPixels;
@@ -229,7 +260,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
                 rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0);
                 bool prim = false, scat_ok = false, sec = false;
                 f3 colour = mk(0, 0, 0);
-                if (active) prim = parity_world_hit(S, A.n_spheres, ray, 0.001f, FMAX, FMAX, rec);
+                PCount pc1{}, pc2{};
+                if (active) prim = parity_world_hit<COUNT>(S, A.n_spheres, ray, 0.001f, FMAX, FMAX, rec, pc1);
                 if (prim) {
                     // material hard-wired to index 2; texture looked up with SCREEN-space (uu,vv) (layer.rs:345-351)
                     const MirtMaterial m2 = S.mats[2];
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
                     sc.d = unit - k * rec.n;
                     scat_ok = dot_nofma(sc.d, rec.n) > 0.0f;
                     if (scat_ok) {
-                        sec = parity_world_hit(S, A.n_spheres, sc, 0.001f, FMAX, FMAX, rec);
+                        sec = parity_world_hit<COUNT>(S, A.n_spheres, sc, 0.001f, FMAX, FMAX, rec, pc2);
                         if (sec) {
                             // (n.normalize() * 255.0 / 2.0) * (albedo * fuzzy)  layer.rs:364-372
                             const float norm = sqrt_(dot_nofma(rec.n, rec.n));
@@ -271,11 +303,25 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
                     done = true;
                 }
                 hits_before += (uint32_t)__popcll(prim_mask);
+                if constexpr (COUNT) {
+                    // the sequential loop reaches sample s only if no earlier sample terminated the pixel
+                    const bool reached = active && (term_mask == 0ull || lane <= (uint32_t)__builtin_ctzll(term_mask));
+                    if (reached) {
+                        const bool second = prim && !exhausted && scat_ok;      // the scattered ray is traced
+                        work.add(kCntLaneIters);                               // samples executed
+                        work.add(kCntRays, second ? 2u : 1u);
+                        work.add(kCntTests, pc1.tests + (second ? pc2.tests : 0u));
+                        work.add(kCntRoots, pc1.roots + (second ? pc2.roots : 0u));
+                        work.add(kCntHits, pc1.hits + (second ? pc2.hits : 0u));
+                        if (prim && !exhausted) work.add(kCntScatter1);       // scatter_metal (layer.rs:353)
+                    }
+                }
             }
             if (!done) rgba = pack_rgba(sat_u8(v * 255.0f), sat_u8(u * 255.0f), sat_u8(255.0f));   // layer.rs:380
             if (lane == p) my_px = rgba;
         }
         if (lane < kStripPixels && base + lane < npix) A.out[base + lane] = my_px;
+        work.flush(A.counters, lane);
     }
 }
 
@@ -298,23 +344,6 @@ struct Rng {
         const uint32_t word = ((old >> ((old >> 28) + 4u)) ^ old) * 277803737u;
         state = (word >> 22) ^ word;
         return (float)state * 0x1p-32f;
-    }
-};
-
-template <bool COUNT>
-struct Work {
-    uint32_t c[kNumCounters];
-    MIRT_DEV void clear() { if constexpr (COUNT) { for (uint32_t i = 0; i < kNumCounters; ++i) c[i] = 0; } }
-    MIRT_DEV void add(uint32_t slot, uint32_t n = 1) { if constexpr (COUNT) c[slot] += n; }
-    MIRT_DEV void flush(unsigned long long* g, uint32_t lane)
-    {
-        if constexpr (COUNT) {
-            for (uint32_t i = 0; i < kNumCounters; ++i) {
-                const unsigned long long t = wave_sum_u64(c[i]);
-                if (lane == 0 && t) atomicAdd(&g[i], t);
-                c[i] = 0;
-            }
-        }
     }
 };
 
@@ -424,8 +453,11 @@ struct GridLds {
     const unsigned short* items;
 };
 
-MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best)
+template <bool COUNT>
+MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best,
+                          Work<COUNT>& work)
 {
+    if (alive) work.add(kCntTests);                              // grid builds count the tests a lane really performs
     const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
     const f3 oc = ro - mk(s4.x, s4.y, s4.z);
     const float b = dot(oc, rd);
@@ -436,6 +468,7 @@ MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, 
         const float t0 = (-b - sq) * inv_a;
         const float t1 = (-b + sq) * inv_a;
         const bool first = t0 > kMinT;
+        work.add(kCntRoots, first ? 1u : 2u);
         const float f = first ? t0 : t1;                          // first root above MIN_T
         const bool valid = first || (t1 > kMinT);
         const bool better = (f < closest) || (f == closest && (int)i < best);
@@ -458,14 +491,17 @@ MIRT_DEV GridLds stage_grid(const RenderArgs& A, unsigned char* gdst)
     return G;
 }
 
-MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool alive, float& closest_out)
+template <bool COUNT>
+MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool alive, float& closest_out, Work<COUNT>& work,
+                              uint32_t lane)
 {
     const float a = dot(rd, rd);
     const float inv_a = rcp_(a);
     float closest = kMaxT;
     int best = -1;
     const GridHeader& H = *G.h;
-    for (uint32_t j = 0; j < H.n_big; ++j) test_sphere(S, G.big[j], ro, rd, a, inv_a, alive, closest, best);
+    if (alive) work.add(kCntRays);
+    for (uint32_t j = 0; j < H.n_big; ++j) test_sphere<COUNT>(S, G.big[j], ro, rd, a, inv_a, alive, closest, best, work);
 
     // clip the ray against the grid's box
     const f3 org = mk(H.org[0], H.org[1], H.org[2]);
@@ -509,6 +545,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 
     while (__ballot(walking)) {
         uint32_t first = 0, count = 0;
+        if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
         if (walking) {
             const uint32_t c = (uint32_t)((cz * dy + cy) * dx + cx);
             first = G.start[c];
@@ -517,7 +554,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
         for (uint32_t n = 0; __ballot(n < count); ++n) {
             const bool on = n < count;
             const uint32_t i = on ? (uint32_t)G.items[first + n] : 0u;
-            test_sphere(S, i, ro, rd, a, inv_a, on, closest, best);
+            test_sphere<COUNT>(S, i, ro, rd, a, inv_a, on, closest, best, work);
         }
         if (walking) {
             const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
@@ -748,7 +785,7 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
         }
         float closest;
         int best;
-        if constexpr (GRID) best = nearest_hit_grid(S, G, ro, rd, alive, closest);
+        if constexpr (GRID) best = nearest_hit_grid<COUNT>(S, G, ro, rd, alive, closest, work, lane);
         else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
         if (alive) {
             if (best >= 0) {
@@ -1080,7 +1117,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
             float closest;
             int nb;
-            if constexpr (GRID) nb = nearest_hit_grid(S, G, ro, rd, trace, closest);
+            if constexpr (GRID) nb = nearest_hit_grid<COUNT>(S, G, ro, rd, trace, closest, work, lane);
             else nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
             const bool hit = trace && nb >= 0;
             if (hit) work.add(kCntHits);
@@ -1225,15 +1262,18 @@ static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a,
     return hipGetLastError();
 }
 
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, hipStream_t stream)
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
 {
-    return launch_with_lds(render_parity_kernel, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
+    return count ? launch_with_lds(render_parity_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), a, stream)
+                 : launch_with_lds(render_parity_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const dim3 g(grid_blocks), b(kBlockThreads);
+    if (count && use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, true>, g, b, a, stream)
+                                        : launch_with_lds(render_pt_strip_kernel<true, false, true>, g, b, a, stream);
     if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
                             : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
     if (by_pixel) {
@@ -1262,9 +1302,11 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 
 // grid build of the default pool geometry: LDS (scene + grid + pools) bounds it to a few blocks per CU, so the
 // register budget is not the limit
-static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool hosek, uint32_t nq, hipStream_t stream)
+static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(256);
+    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, true, 5, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, false, 5, true>, g, b, a, stream);
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 3, true>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 3, true>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 5, true>, g, b, a, stream)
@@ -1301,7 +1343,7 @@ uint32_t pool_scatter_queues(uint32_t n_routines, bool count) { return (!count &
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
-    if (a.grid) return launch_pool_grid(a, grid_blocks, hosek, nq, stream);     // host: default geometry, not counting
+    if (a.grid) return launch_pool_grid(a, grid_blocks, count, hosek, nq, stream);     // host: default geometry only
     switch (cfg) {
     case 1:  return launch_pool_cfg<256, 128>(a, grid_blocks, count, hosek, nq, stream);
     case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, nq, stream);
