@@ -628,7 +628,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
     const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
-    // counting launches keep the reference's flat scan (their counters are then the oracle's) unless
+    // counting launches keep the reference's flat scan (their counters are then the reference's) unless
     // MIRT_FLAG_COUNT_GRID asks for the work of the grid build that renders the scene in production
     const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
     const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pc.lds_bytes;

@@ -215,7 +215,7 @@ MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay
 
 // COUNT = true additionally tallies the work the REFERENCE's sequential sample loop performs (it returns at
 // the first terminating sample): only the samples up to and including that one are counted, although all 64
-// lanes of a batch compute theirs.  Same meaning as the oracle's counters (tests/test_gpu_parity.py).
+// lanes of a batch compute theirs.  The CPU check in tests/test_gpu_parity.py tallies the same quantities.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs A)
 {
