@@ -1,30 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the per-pixel ray-trace path on MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU,
-  RCCL); RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|parity]
 
-Workload (BASELINE.json configs[2], the configuration `metric` is quoted on): path-traced mode,
-three-sphere diffuse+metal+dielectric scene (reference src/main.rs:539-541), 1920x1080, 1000 spp,
-8 bounces, synthetic scene tables already resident in HBM.  One "step" = one full frame:
-every rank renders its row tiles, ONE gather brings them to rank 0, rank 0 assembles the RGBA8
-frame.  value = pixels x spp x K / wall seconds / 1e6 (whole job, all ranks; total work is fixed
-as N grows -> "strong" scaling).
+One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this script LAUNCHES its own ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, fresh child
+processes, started before this process has touched torch or the GPU) and returns their exit code; started
+under torch.distributed.run it is one of those ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
+
+Default workload = BASELINE.json configs[2], the configuration `metric` is quoted on: path-traced mode,
+three-sphere diffuse+metal+dielectric scene (reference src/main.rs:539-541), 1920x1080, 1000 spp, 8 bounces,
+synthetic scene tables already resident in HBM.  One "step" = one full frame: every rank renders its row
+tiles, ONE gather brings them to rank 0, rank 0 assembles the RGBA8 frame.  value = pixels x spp x K / wall
+seconds / 1e6 (whole job, all ranks; total work is fixed as N grows -> "strong" scaling).
+`--config` selects the other BASELINE configurations (same JSON shape; `config.workload` names them).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     fp32 vector-ALU roofline of the render kernel (north_star: "scalar-ray fp32 FMA,
-               no MFMA"): achieved = ALGORITHMIC flops per launch (work counters of one counting
-               launch x the per-unit figures of SURVEY §8d / DESIGN.md) / the kernel's average
-               duration measured with HIP events on the launch stream inside the timed region.
-  cpu_baseline the CPU oracle (a port: the reference is Rust and cannot be built here) timed on
-               the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      fp32 vector-ALU roofline of the render kernel (north_star: "scalar-ray fp32 FMA, no MFMA"):
+                achieved = ALGORITHMIC flops per launch (work counters of one counting launch x the per-unit
+                figures of SURVEY §8d / DESIGN.md) / the kernel's average duration measured with HIP events on
+                the launch stream inside the timed region.
+  cpu_baseline  the CPU oracle (a port: the reference is Rust and cannot be built here) timed on the host cores
+                on a bounded sample of the same workload (rank 0, N = 1 only), plus `layer_rs`: the reference's
+                own CPU loop (`Layer::set_data`, parity mode) restated, faithful (with its per-sample
+                world.clone() allocations) and clean, on 1 thread and on all cores.
+  verified_rows rows of the frame the timed region produced, compared byte for byte with oracle rows rendered at
+                the full sample count (the checker, after the clock has stopped).
+
+`--dry-run` rehearses the N-rank path without a GPU (gloo, CPU tensors, a pattern renderer instead of the HIP
+kernel): it proves that the ranks start, partition, gather and assemble; it measures nothing.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,26 +45,55 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT)]
 
-WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 1000, 8
+WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 1000, 8            # the headline configuration (BASELINE configs[2])
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CU x 256 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+
+# BASELINE.json `configs` as bench workloads (config 1 is the CPU-only plumbing case: a parity test, not a bench line)
+CONFIGS = {
+    "2": dict(scene="single_sphere", width=1920, height=1080, spp=100, mode="pt",
+              workload="BASELINE configs[1]: single unit sphere (metal), 1920x1080, 100 spp, path-traced mode, 8 bounces"),
+    "3": dict(scene="three_spheres", width=WIDTH, height=HEIGHT, spp=SPP, mode="pt",
+              workload="BASELINE configs[2]: path-traced 3-sphere scene, checker-diffuse ground + glass + metal "
+                       "(src/main.rs:539-541), 1920x1080, 1000 spp, 8 bounces, gradient sky, seed 0"),
+    "4": dict(scene="earth", width=1920, height=1080, spp=1000, mode="pt",
+              workload="BASELINE configs[3]: earth-textured sphere (assets/earthmap.jpeg, 1024x512 texels) over the checker "
+                       "ground, 1920x1080, 1000 spp, 8 bounces"),
+    "5": dict(scene="rtiow_final", width=3840, height=2160, spp=500, mode="pt",
+              workload="BASELINE configs[4] CUT TO 500 spp: RTIOW final scene (484 spheres, generated, seed 0x5EED), 3840x2160, "
+                       "8 bounces; 500 spp = the samples one GPU renders of the 8-GPU 4000-spp job, so that a step lasts < 1 s"),
+    "parity": dict(scene="layer_scene", width=1920, height=1080, spp=1000, mode="parity",
+                   workload="parity mode (layer.rs semantics, bit-faithful) on the 6-sphere Layer::scene (layer.rs:90-123), "
+                            "1920x1080, 1000 spp nominal (the reference's loop returns at the first terminating sample)"),
+}
+VERIFY_ROWS = {1080: (0, 269, 540, 811, 1079), 2160: (0, 1080, 1500, 2159)}
 
 # algorithmic flops per unit of work (DESIGN.md "Algorithmic work")
 FLOPS = {
     "sample": 17 + 12 + 6,          # ray generation + thin-lens offset + throughput*colour & fixed-point convert
+    "parity_sample": 17,            # make_ray + the two jitter adds
     "test": 23,                     # ray-sphere test up to the discriminant
     "root": 4,                      # sqrt, negate, add/sub, scale
     "hit": 21,                      # p, n, u/v
     "scatter": [45, 35, 50, 54, 35],  # lambertian, metal, dielectric, checkerboard(+9 over lambertian), missing
+    "parity_scatter": 20,           # scatter_metal: unit_vertor + reflect + dot
     "sky_gradient": 18,
     "sky_hosek": 360,
+    "grid_ray": 45,                 # clip against the grid box, entry cell, per-axis crossing parameters and increments
+    "grid_cell": 10,                # exit parameter, stop test, axis choice, step
 }
 
 
-def algorithmic_flops(st: dict, hosek: bool = False) -> float:
+def algorithmic_flops(st: dict, hosek: bool = False, mode: str = "pt", grid: bool = False) -> float:
+    """Flops the REFERENCE formulas need for the work counted in `st` (not the instructions executed)."""
+    if mode == "parity":
+        return float(FLOPS["parity_sample"] * st["lane_iterations"] + FLOPS["test"] * st["sphere_tests"] + FLOPS["root"] * st["roots"]
+                     + FLOPS["hit"] * st["hits"] + FLOPS["parity_scatter"] * st["scatter"][1])
     f = FLOPS["sample"] * st["samples"] + FLOPS["test"] * st["sphere_tests"] + FLOPS["root"] * st["roots"]
     f += FLOPS["hit"] * st["hits"] + sum(w * n for w, n in zip(FLOPS["scatter"], st["scatter"]))
     f += (FLOPS["sky_hosek"] if hosek else FLOPS["sky_gradient"]) * st["sky_misses"]
+    if grid:
+        f += FLOPS["grid_ray"] * st["rays"] + FLOPS["grid_cell"] * st.get("grid_cells", 0)
     return float(f)
 
 
@@ -71,46 +113,200 @@ def profiled_traffic(kernel: str):
     return best
 
 
-def build_scene(m):
-    scene, cam = m.scenes.three_spheres()
+def kernel_uses_grid(name: str) -> bool:
+    """GRID template argument of the kernel names `Context.last_kernel()` reports (mirt_ctx_last_kernel)."""
+    if "<" not in name:
+        return False
+    targs = name[name.index("<") + 1:name.rindex(">")].split(",")
+    if name.startswith("render_pt_pool_kernel"):
+        return targs[-1] == "true"
+    if name.startswith("render_pt_strip_kernel"):
+        return targs[2] == "true"
+    return False
+
+
+def build_scene(m, cfg: dict):
+    w, h = cfg["width"], cfg["height"]
+    if cfg["scene"] == "layer_scene":                     # Layer::new + set_global_data under the default fly camera
+        rp = m.RenderParams(camera=m.FlyCameraController.default().renderer_camera(), viewport_size=(w, h))
+        layer = m.Layer.new([w, h], rp)
+        layer.set_global_data()
+        return layer.scene_data()
+    scene, cam = m.scenes.CONFIGS[cfg["scene"]]()
     mats, texels = m.flatten_materials(scene.materials)
-    gcam = m.GpuCamera.new(cam, (WIDTH, HEIGHT))
+    gcam = m.GpuCamera.new(cam, (w, h))
     return m.SceneData(gcam.c, [s.to_c() for s in scene.spheres], mats, texels)
 
 
-def cpu_baseline(m, sd, target_seconds: float = 15.0) -> dict:
+def base_params(m, cfg: dict, flags: int = 0):
+    mode = m.MIRT_MODE_PT if cfg["mode"] == "pt" else m.MIRT_MODE_PARITY
+    return m.make_params(cfg["width"], cfg["height"], cfg["spp"], mode=mode, num_bounces=BOUNCES, flags=flags)
+
+
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(m, sd, cfg: dict, target_seconds: float = 12.0) -> dict:
     """Time the CPU oracle on a bounded sample of the SAME workload (same frame, fewer spp)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_binding as ob     # checker / baseline only
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
+    w, h, full = cfg["width"], cfg["height"], cfg["spp"]
+    if cfg["mode"] == "parity":
+        lr = layer_rs_baseline(m, ob, sd, w, h)
+        best = lr["clean_all_cores"]
+        return {"value": best["msamples_per_s"], "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": f"Layer::scene {w}x{h} at {lr['spp']} spp (the reference's default), clean variant on all cores; see layer_rs",
+                "layer_rs": lr}
     spp, secs = 4, 0.0
     for _ in range(4):                                   # grow the sample until it is worth ~target_seconds of CPU work
-        p = m.make_params(WIDTH, HEIGHT, spp, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
+        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES)
         ob.render(sd, p, n_threads=cores)
         secs = ob.stats()["kernel_ms"] / 1e3
-        if secs >= 0.6 * target_seconds or spp >= SPP:
+        if secs >= 0.6 * target_seconds or spp >= full:
             break
-        spp = int(max(spp + 1, min(SPP, round(spp * target_seconds / max(secs, 1e-3)))))
-    return {"value": round(WIDTH * HEIGHT * spp / secs / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+        spp = int(max(spp + 1, min(full, round(spp * target_seconds / max(secs, 1e-3)))))
+    return {"value": round(w * h * spp / secs / 1e6, 3), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
-            "sample": f"same scene and frame ({WIDTH}x{HEIGHT}, {BOUNCES} bounces) at {spp} spp instead of {SPP} "
+            "sample": f"same scene and frame ({w}x{h}, {BOUNCES} bounces) at {spp} spp instead of {full} "
                       f"({secs:.1f} s; rate is spp-independent); oracle = C restatement, OpenMP over rows; "
                       f"the Rust reference cannot be built (no toolchain)"}
 
 
-def main() -> int:
+def layer_rs_baseline(m, ob, sd_layer, w: int, h: int, spp: int = 2) -> dict:
+    """The reference's own CPU loop (`Layer::set_data`, layer.rs:264-282 and callees) restated in C and timed on the
+    host: `faithful` reproduces the two world.clone() allocation rounds per sample (layer.rs:332,359), `clean` does not
+    allocate.  spp = 2 is the reference's default (mod.rs:605-613); parity-mode work is not proportional to spp (the
+    loop returns at the first terminating sample), so the rate is quoted at that default only."""
+    cores = host_cores()
+    p = m.make_params(w, h, spp)
+    out = {"spp": spp, "frame": f"{w}x{h}", "scene": "Layer::scene (6 spheres, layer.rs:90-123)", "cores": cores}
+    for name, variant in (("faithful", ob.FAITHFUL), ("clean", ob.CLEAN)):
+        for label, nt in (("1_thread", 1), ("all_cores", cores)):
+            reps, secs = 0, 0.0
+            while secs < 0.4 and reps < 50:
+                ob.render(sd_layer, p, n_threads=nt, variant=variant)
+                secs += ob.stats()["kernel_ms"] / 1e3
+                reps += 1
+            out[f"{name}_{label}"] = {"msamples_per_s": round(w * h * spp * reps / secs / 1e6, 3), "threads": nt, "repeats": reps}
+    return out
+
+
+def verify_rows(m, sd, cfg: dict, frame_host, budget_seconds: float = 40.0) -> list:
+    """Rows of the TIMED frame against oracle rows at the full sample count; the checker runs after the clock stopped."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
+    import oracle_binding as ob
+
+    t0, out = time.perf_counter(), []
+    for r in VERIFY_ROWS.get(cfg["height"], (0, cfg["height"] // 2, cfg["height"] - 1)):
+        if time.perf_counter() - t0 > budget_seconds:
+            break
+        p = base_params(m, cfg)
+        p.row_begin, p.row_end = r, r + 1
+        want = ob.render(sd, p, n_threads=host_cores())
+        out.append({"row": r, "spp": cfg["spp"], "equal": bool(np.array_equal(frame_host[r:r + 1], want))})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# --dry-run: the N-rank path without a GPU (pattern renderer, gloo)
+# ------------------------------------------------------------------------------------------------
+
+def pattern_rows(rows, width: int):
+    """RGBA8 rows whose bytes are a function of the ABSOLUTE (row, x) only — what a correct partition must reassemble."""
+    import numpy as np
+    rows = np.asarray(rows, dtype=np.uint32)[:, None]
+    xs = np.arange(width, dtype=np.uint32)[None, :]
+    img = np.empty((rows.shape[0], width, 4), dtype=np.uint8)
+    img[..., 0] = (rows * 7 + xs) & 255
+    img[..., 1] = (rows ^ (xs >> 2)) & 255
+    img[..., 2] = ((rows >> 3) + (xs >> 5)) & 255
+    img[..., 3] = 255
+    return img
+
+
+class PatternContext:
+    """Stand-in for `Context` in --dry-run: fills a rank's compact buffer with pattern_rows() of the rows the
+    params select, and de-interleaves on the host with the same `assemble_host` the CPU tests use."""
+
+    def __init__(self, m):
+        self.m, self.device, self.launches = m, 0, 0
+
+    @staticmethod
+    def _view(ptr: int, shape):
+        import numpy as np
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr)).reshape(shape)
+
+    def render_device(self, params, d_ptr: int, nbytes: int, stream=None) -> None:
+        m = self.m
+        rows = [m.params_out_row_index(params, i) for i in range(m.params_out_rows(params))]
+        assert nbytes >= len(rows) * params.width * 4
+        self._view(d_ptr, (len(rows), params.width, 4))[:] = pattern_rows(rows, params.width)
+        self.launches += 1
+
+    def deinterleave_device(self, params, d_parts: int, part_stride: int, d_out: int, out_nbytes: int, stream=None) -> None:
+        m = self.m
+        world, w = params.n_parts, params.width
+        parts = self._view(d_parts, (world, part_stride // (w * 4), w, 4))
+        band = m.multi_gpu.band_rows(params)
+        self._view(d_out, (band, w, 4))[:] = m.multi_gpu.assemble_host(parts, params, world, params.tile_rows)
+
+    def stats(self) -> dict:
+        n, self.launches = self.launches, 0
+        return {"kernel_ms_total": 0.0, "launches": n, "kernel_ms": 0.0}
+
+    def close(self) -> None:
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: N > 1 from a bare shell
+# ------------------------------------------------------------------------------------------------
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Start N fresh rank processes through torch.distributed.run and wait for them.  This process has not
+    imported torch and never touches the GPU; the ranks are ordinary children (no exec of a GPU process)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="3")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline, verified_rows)")
     ap.add_argument("--tile-rows", type=int, default=4)
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank path on CPU (gloo, pattern renderer); measures nothing")
+    return ap.parse_args(argv)
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)                       # BEFORE torch / the GPU are touched in this process
 
     import torch
     import torch.distributed as dist
@@ -120,31 +316,50 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the render path has no CPU fallback (use --dry-run to rehearse the rank plumbing)", file=sys.stderr)
         return 3
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import weekend_raytracer_wgpu_amd as m
 
+    cfg = dict(CONFIGS[args.config])
+    if dry:                                               # small frame: the pattern renderer is numpy
+        cfg.update(width=192, height=108, spp=1)
+    w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
+    device = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+
     # everything below is queued on ONE non-default stream: renders (through the C ABI), the RCCL gather (which
     # orders itself against torch's current stream) and the de-interleave
-    torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
+    if not dry:
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
 
-    sd = build_scene(m)
-    ctx = m.Context(local_rank)
-    ctx.set_scene(sd)                                   # inputs resident in HBM before the timed region
-    base = m.make_params(WIDTH, HEIGHT, SPP, mode=m.MIRT_MODE_PT, num_bounces=BOUNCES,
-                         flags=int(os.environ.get("MIRT_BENCH_FLAGS", "0"), 0))      # e.g. 0x10 strip / 0x20 pool (A/B runs)
+    sd = None
+    if dry:
+        ctx = PatternContext(m)
+    else:
+        sd = build_scene(m, cfg)
+        ctx = m.Context(local_rank)
+        ctx.set_scene(sd)                                   # inputs resident in HBM before the timed region
+    base = base_params(m, cfg, flags=int(os.environ.get("MIRT_BENCH_FLAGS", "0"), 0))   # e.g. 0x10 strip / 0x20 pool (A/B runs)
     # N > 1: the gather of frame i overlaps the render of frame i+1 (double-buffered parts, async collective);
     # every frame is complete on rank 0 before the timed region ends (flush).  MIRT_BENCH_PIPELINE=0: one frame at a time.
     pipelined = world > 1 and os.environ.get("MIRT_BENCH_PIPELINE", "1") != "0"
-    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined)
+    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined, device=device)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
@@ -154,63 +369,79 @@ def main() -> int:
         # communicator set-up, not a step: RCCL opens its point-to-point channels on first use, so push one
         # gather of the (still empty) buffers through before anything is timed
         m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
-        torch.cuda.synchronize()
+        sync()
         barrier()
 
     for _ in range(args.warmup):
         frame.step()
     frame.flush()
-    torch.cuda.synchronize()
+    sync()
     ctx.stats()                                         # drain the event pool: the timed region starts clean
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame.step()
     frame.flush()                                       # all K frames assembled on rank 0
-    torch.cuda.synchronize()
+    sync()
     barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()                                    # HIP-event time of the K kernels of the timed region
+    kernel_ms = st["kernel_ms_total"] / max(1, st["launches"])
+    red_dev = torch.device("cpu") if dry else torch.device("cuda")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([st["kernel_ms_total"] / max(1, st["launches"])], dtype=torch.float64, device="cuda")
-        kmax = k.clone()
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        kernel_ms_max = float(kmax.item())
-        per_rank = torch.zeros(world, dtype=torch.float64, device="cuda")     # every rank's kernel time, so that
-        per_rank[rank] = k[0]                                                  # imbalance is visible
+        per_rank = torch.zeros(world, dtype=torch.float64, device=red_dev)     # every rank's kernel time, so that
+        per_rank[rank] = kernel_ms                                              # imbalance is visible
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
         kernel_ms_per_rank = [round(float(x), 4) for x in per_rank.tolist()]
+        kernel_ms_max = max(kernel_ms_per_rank)
     else:
-        kernel_ms_max = st["kernel_ms_total"] / max(1, st["launches"])
-        kernel_ms_per_rank = [round(kernel_ms_max, 4)]
-    kernel_ms = st["kernel_ms_total"] / max(1, st["launches"])
+        kernel_ms_max = kernel_ms
+        kernel_ms_per_rank = [round(kernel_ms, 4)]
+    partition = ("whole frame" if world == 1 else
+                 f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather per frame"
+                 + (" (overlapping the next frame's render)" if pipelined else ""))
+    total_samples = w * h * spp
 
-    # one counting launch (outside the timed region) gives the exact work of this rank's launch
+    if dry:
+        ok = True
+        if rank == 0:
+            import numpy as np
+            ok = bool(np.array_equal(frame.frame.numpy(), pattern_rows(range(h), w)))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "frames_verified": ok, "launches_rank0": st["launches"], "backend": "gloo" if world > 1 else "none",
+                              "kernel_ms_per_rank": kernel_ms_per_rank,
+                              "config": {"workload": f"DRY RUN ({w}x{h} pattern frame, no GPU, nothing measured)", "partition": partition}}),
+                  flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0 if ok else 4
+
+    # one counting launch (outside the timed region) gives the exact work of this rank's launch; for grid builds
+    # (many-sphere scenes) it counts the kernel that actually runs, not the flat scan
+    kernel_name = ctx.last_kernel()
+    uses_grid = kernel_uses_grid(kernel_name)
     pc = m.multi_gpu.part_params(base, rank, world, args.tile_rows)
-    pc.flags |= m.MIRT_FLAG_COUNT_WORK
-    ctx.render_device(pc, frame.local.data_ptr() if world > 1 else frame.frame.data_ptr(),
-                      frame.rows * WIDTH * 4, torch.cuda.current_stream().cuda_stream)
+    pc.flags |= m.MIRT_FLAG_COUNT_WORK | (m.MIRT_FLAG_COUNT_GRID if uses_grid else 0)
+    scratch = torch.empty((frame.max_rows if world > 1 else frame.frame.shape[0], w, 4), dtype=torch.uint8, device=device)
+    ctx.render_device(pc, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     work = ctx.stats()
 
-    result = None
     if rank == 0:
-        total_samples = WIDTH * HEIGHT * SPP
         value = total_samples * args.steps / elapsed / 1e6
-        flops = algorithmic_flops(work)
-        kernel_name = "render_pt_pool_kernel<256,112,false,false>"     # default schedule for spp >= 48 (mirt_api.hip)
-        if base.flags & m.MIRT_FLAG_KERNEL_STRIP:
-            kernel_name = "render_pt_strip_kernel<false,false>"
+        flops = algorithmic_flops(work, mode=cfg["mode"], grid=uses_grid)
         traffic = profiled_traffic(kernel_name) if world == 1 else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
-        out_bytes = frame.rows * WIDTH * 4
-        in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96
+        out_bytes = frame.rows * w * 4
+        in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96 + 12 * int(sd.texels.shape[0])
+        lane_slots = 64 * work["wave_iterations"]
         result = {
-            "metric": "Msamples/sec (pixels x spp) at 1920x1080, 1000 spp",
+            "metric": "Msamples/sec (pixels x spp) at 1920x1080, 1000 spp" if args.config == "3" else "Msamples/sec (pixels x spp)",
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -222,13 +453,8 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[2]: path-traced 3-sphere scene, checker-diffuse ground + glass + metal "
-                            "(src/main.rs:539-541), 1920x1080, 1000 spp, 8 bounces, gradient sky, seed 0",
-                "width": WIDTH, "height": HEIGHT, "spp": SPP, "num_bounces": BOUNCES, "mode": "pt",
-                "partition": "whole frame" if world == 1 else f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather per frame"
-                             + (" (overlapping the next frame's render)" if pipelined else ""),
-            },
+            "config": {"workload": cfg["workload"], "width": w, "height": h, "spp": spp, "num_bounces": BOUNCES,
+                       "mode": cfg["mode"], "partition": partition},
             "roofline": {
                 "bound": "valu_fp32",
                 "achieved": round(achieved_tflops, 3),
@@ -244,20 +470,27 @@ def main() -> int:
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
                 "kernel_ms_per_rank": kernel_ms_per_rank,
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
-                "flop_per_sample": round(flops / work["samples"], 2),
+                "flop_per_sample": round(flops / max(1, work["samples"]), 2),
                 "grays_per_s": round(work["rays"] / (kernel_ms * 1e-3) / 1e9, 3),
                 "gtests_per_s": round(work["sphere_tests"] / (kernel_ms * 1e-3) / 1e9, 3),
-                "lane_utilization": round(work["lane_iterations"] / max(1, 64 * work["wave_iterations"]), 4),
+                "lane_utilization": round(work["lane_iterations"] / lane_slots, 4) if lane_slots else None,
+                "grid_walk_lane_utilization": (round(work["grid_cells"] / (64 * work["grid_wave_cells"]), 4)
+                                               if work.get("grid_wave_cells") else None),
                 "hbm": {"algorithmic_bytes_per_launch": out_bytes + in_bytes,
                         "achieved_gbs": round((out_bytes + in_bytes) / (kernel_ms * 1e-3) / 1e9, 4),
                         "peak_gbs": PEAK_HBM_GBS},
-                "note": "fp32 vector-ALU roofline (no MFMA on this path; HBM traffic is ~8 MB per launch); "
+                "note": "fp32 vector-ALU roofline (no MFMA on this path; HBM traffic is the framebuffer + the scene tables once); "
                         "rocprofv3 summaries under profiles/",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(m, sd)
+            result["cpu_baseline"] = cpu_baseline(m, sd, cfg)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+            if cfg["mode"] == "pt":                          # the reference's own CPU loop beside it (north_star's last sentence)
+                sys.path.insert(0, str(ROOT / "tests"))
+                import oracle_binding as ob
+                result["cpu_baseline"]["layer_rs"] = layer_rs_baseline(m, ob, build_scene(m, CONFIGS["parity"]), 1920, 1080)
+            result["verified_rows"] = verify_rows(m, sd, cfg, frame.frame.cpu().numpy())
         print(json.dumps(result), flush=True)
 
     ctx.close()

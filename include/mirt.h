@@ -277,6 +277,12 @@ int mirt_ctx_render(MirtContext* ctx, const MirtParams* params, uint8_t* out_rgb
 int mirt_ctx_render_device(MirtContext* ctx, const MirtParams* params, void* d_out_rgba8,
                            size_t out_len, void* hip_stream);
 
+/* Name of the render kernel the LAST render call on this context launched (the schedule is chosen per call from
+ * mode, spp, scene and flags), e.g. "render_pt_pool_kernel<256,112,6,false,false,3,false>" — the template
+ * arguments as they appear in rocprofv3 kernel traces, without the `u` suffixes.  "" before the first render.
+ * The pointer stays valid until the next render call or mirt_ctx_destroy. */
+const char* mirt_ctx_last_kernel(const MirtContext* ctx);
+
 /* Block until everything the context queued has finished. */
 int mirt_ctx_synchronize(MirtContext* ctx);
 /* Stats of the last completed render call (synchronises the context first). */

@@ -33,3 +33,61 @@ def test_workload_constants_are_the_baseline_config():
     assert "1920" in cfg["metric"] and "1000 spp" in cfg["metric"]
     assert (bench.WIDTH, bench.HEIGHT, bench.SPP) == (1920, 1080, 1000)
     assert bench.PEAK_FP32_VECTOR_TFLOPS == 157.3
+
+
+def test_parity_and_grid_flop_formulas():
+    st = {"samples": 10, "sphere_tests": 100, "roots": 7, "hits": 5, "scatter": [0, 3, 0, 0, 0], "sky_misses": 9,
+          "lane_iterations": 4, "rays": 6, "grid_cells": 50}
+    assert bench.algorithmic_flops(st, mode="parity") == 17 * 4 + 23 * 100 + 4 * 7 + 21 * 5 + 20 * 3
+    flat = bench.algorithmic_flops(st)
+    assert bench.algorithmic_flops(st, grid=True) == flat + 45 * 6 + 10 * 50
+
+
+def test_kernel_name_parsing():
+    assert bench.kernel_uses_grid("render_pt_pool_kernel<256,112,3,false,false,5,true>")
+    assert not bench.kernel_uses_grid("render_pt_pool_kernel<256,112,6,false,false,3,false>")
+    assert bench.kernel_uses_grid("render_pt_strip_kernel<false,false,true,false>")
+    assert not bench.kernel_uses_grid("render_pt_strip_kernel<false,false,false,true>")
+    assert not bench.kernel_uses_grid("render_parity_kernel<false>") and not bench.kernel_uses_grid("")
+
+
+def test_every_baseline_config_has_a_bench_workload():
+    cfg = json.loads((ROOT / "BASELINE.json").read_text())
+    assert len(cfg["configs"]) == 5                       # configs[0] is the CPU-only plumbing case (a parity test)
+    assert set(bench.CONFIGS) == {"2", "3", "4", "5", "parity"}
+    assert bench.parse_args([]).config == "3" and bench.parse_args([]).gpus == 1
+    for c in bench.CONFIGS.values():
+        assert {"scene", "width", "height", "spp", "mode", "workload"} <= set(c)
+
+
+def _bare_env():
+    import os
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start 2 fresh ranks itself (before touching the GPU),
+    reach init_process_group, run the pipelined partition -> gather -> assemble path and print ONE JSON line from
+    rank 0.  --dry-run swaps the HIP kernel for a pattern renderer and RCCL for gloo; everything else is the code
+    the driver's SCALE run executes."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=_bare_env(), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["frames_verified"] and d["launches_rank0"] == 3
+    assert len(d["kernel_ms_per_rank"]) == 2 and "2 ranks + 1 gather per frame" in d["config"]["partition"]
+
+
+def test_bench_rejects_a_world_size_mismatch():
+    import os
+    import subprocess
+    env = dict(_bare_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd="/tmp")
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

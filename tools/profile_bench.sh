@@ -1,26 +1,28 @@
 #!/bin/bash
-# Profile the bench workload on the GPU box (run from the repo root through gpurun):
-#   pass 1: kernel trace + stats   pass 2..: PMC counters, each in its own run (no --stats mixing of domains)
-# Summaries land under gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
+# Profile one bench workload on the GPU box (run from the repo root through gpurun):
+#   tools/profile_bench.sh TAG [CONFIG] [STEPS]
+#   pass 0: the plain bench line (kernel name, HIP-event kernel time)      -> gpurun_out/prof_TAG/bench.json
+#   pass 1: rocprofv3 --kernel-trace --stats                                -> .../trace
+#   pass 2..: PMC counters, each group in its own run (never mixed with other trace domains)
+# Summaries land under gpurun_out/prof_<tag>/; tools/summarize_profile.py copies what is judged into profiles/.
 set -o pipefail
-TAG=${1:-r01}
-STEPS=${2:-3}
+TAG=${1:-r02}
+CONFIG=${2:-3}
+STEPS=${3:-3}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --config $CONFIG --steps $STEPS --warmup 1 --no-cpu-baseline"
+$BENCH > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { tail -20 "$OUT/trace.log"; exit 1; }
 i=0
-if [ "${QUICK:-0}" = "1" ]; then
-  GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
-           "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE GRBM_COUNT")
-else
-  GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
-           "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE GRBM_COUNT" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum")
+GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+         "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE GRBM_COUNT")
+if [ "${QUICK:-0}" != "1" ]; then
+  GROUPS_+=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum")
 fi
 for PMC in "${GROUPS_[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i failed"; tail -5 "$OUT/pmc$i.log"; }
 done
-find "$OUT" -name "*.csv" | head -50
+echo "profiled config $CONFIG -> $OUT"

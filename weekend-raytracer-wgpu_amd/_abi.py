@@ -136,6 +136,7 @@ SYMBOLS = {
     "mirt_ctx_set_camera": (C.c_int, [C.c_void_p, _P(MirtGpuCamera)]),
     "mirt_ctx_render": (C.c_int, [C.c_void_p, _P(MirtParams), C.c_void_p, C.c_size_t]),
     "mirt_ctx_render_device": (C.c_int, [C.c_void_p, _P(MirtParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mirt_ctx_last_kernel": (C.c_char_p, [C.c_void_p]),
     "mirt_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "mirt_ctx_get_stats": (C.c_int, [C.c_void_p, _P(MirtStats)]),
     "mirt_ctx_accum_reset": (C.c_int, [C.c_void_p, _P(MirtParams)]),

@@ -152,6 +152,11 @@ class Context:
         check(lib().mirt_ctx_selftest_math(self._h, out))
         return int(out[0]), int(out[1])
 
+    def last_kernel(self) -> str:
+        """Name of the render kernel the last render call launched (as rocprofv3 traces spell it)."""
+        s = lib().mirt_ctx_last_kernel(self._h)
+        return s.decode() if s else ""
+
     def synchronize(self) -> None:
         check(lib().mirt_ctx_synchronize(self._h))
 

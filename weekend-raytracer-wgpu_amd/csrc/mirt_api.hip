@@ -268,6 +268,7 @@ struct MirtContext {
 
     MirtStats stats{};
     bool      stats_counted = false;
+    char      last_kernel[128] = "";
 };
 
 extern "C" {
@@ -731,9 +732,18 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
-    if (p->mode == MIRT_MODE_PARITY) HIP_TRY(mirt::launch_parity(a, blocks, count, stream));
-    else if (pool) HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
-    else HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
+    const char* tf[2] = { "false", "true" };
+    if (p->mode == MIRT_MODE_PARITY) {
+        HIP_TRY(mirt::launch_parity(a, blocks, count, stream));
+        snprintf(c->last_kernel, sizeof c->last_kernel, "render_parity_kernel<%s>", tf[count]);
+    } else if (pool) {
+        HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
+        mirt::pool_kernel_name(a, pool_cfg, count, pool_nq, c->last_kernel, sizeof c->last_kernel);
+    } else {
+        HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
+        snprintf(c->last_kernel, sizeof c->last_kernel, "render_pt_strip_kernel<%s,%s,%s,%s>", tf[count], tf[hosek], tf[use_grid],
+                 tf[by_pixel && !count]);
+    }
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     if (d_accum) {                                   // resolve/read must see these sums whatever stream they were added on
         HIP_TRY(hipEventRecord(c->ev_accum, stream));
@@ -773,6 +783,8 @@ int mirt_ctx_render(MirtContext* c, const MirtParams* p, uint8_t* out, size_t ou
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MIRT_OK;
 }
+
+const char* mirt_ctx_last_kernel(const MirtContext* c) { return c ? c->last_kernel : ""; }
 
 int mirt_ctx_synchronize(MirtContext* c)
 {

@@ -121,6 +121,8 @@ struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
+// template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID>
+void       pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len);
 uint32_t pool_scatter_queues(uint32_t n_routines, bool count);
 hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,
                           uint32_t flags, hipStream_t stream);

@@ -17,6 +17,8 @@
 // schedules — and any GPU count — give bit-identical images.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add in this file is an explicit fma_().
+#include <cstdio>
+
 #include "mirt_kernels.h"
 #include "mirt_device_math.h"
 
@@ -1351,6 +1353,26 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
     case 4:  return launch_pool_cfg<256, 96, 7>(a, grid_blocks, count, hosek, nq, stream);     // 7 waves per SIMD: <= 72 VGPRs
     default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, nq, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
+}
+
+// mirrors the dispatch of launch_pt_pool / launch_pool_cfg / launch_pool_grid above
+void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len)
+{
+    const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
+    const char* tf[2] = { "false", "true" };
+    uint32_t slots = 112, minw = 6;
+    if (a.grid) { minw = count ? 1 : 3; nq = count ? 5 : (nq <= 3 ? 3 : 5); }
+    else {
+        switch (cfg) {
+        case 1: slots = 128; minw = 1; break;
+        case 2: slots = 64; minw = 1; break;
+        case 3: slots = 256; minw = 1; break;
+        case 4: slots = 96; minw = 7; break;
+        default: break;
+        }
+        if (count) { minw = 1; nq = 5; } else nq = (nq <= 3) ? 3 : 5;
+    }
+    snprintf(out, out_len, "render_pt_pool_kernel<256,%u,%u,%s,%s,%u,%s>", slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
 }
 
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream)

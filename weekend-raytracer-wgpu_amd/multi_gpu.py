@@ -74,7 +74,10 @@ class TiledFrame:
     then no longer meet once per frame; `flush()` completes the frames still in flight."""
 
     def __init__(self, ctx: Context, base: _abi.MirtParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS,
-                 pipelined: bool = False, _rehearse_single_rank: bool = False):
+                 pipelined: bool = False, _rehearse_single_rank: bool = False, device=None):
+        """`ctx` renders (`render_device`) and de-interleaves (`deinterleave_device`) into the buffers allocated
+        here.  `device` defaults to the context's GPU; the CPU rehearsals of the N > 1 path (gloo; tests and
+        `bench.py --dry-run`) pass torch.device("cpu") together with a stand-in context."""
         import torch
 
         self.ctx, self.base, self.rank, self.world, self.tile_rows = ctx, base, rank, world, tile_rows
@@ -83,7 +86,8 @@ class TiledFrame:
         self.max_rows = max_part_rows(base, world, tile_rows)
         self._rehearse = _rehearse_single_rank and world == 1       # drive the collective path with a 1-rank group
         self.pipelined = pipelined and (world > 1 or self._rehearse)
-        dev = torch.device("cuda", ctx.device)
+        dev = torch.device("cuda", ctx.device) if device is None else torch.device(device)
+        self.device = dev
         n_buf = 2 if self.pipelined else 1
         self.locals = [torch.zeros((self.max_rows, base.width, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
         self.local = self.locals[0]
@@ -103,6 +107,10 @@ class TiledFrame:
         self.ctx.deinterleave_device(part_params(self.base, 0, self.world, self.tile_rows), parts.data_ptr(),
                                      self.local.numel(), self.frame.data_ptr(), self.frame.numel(), stream)
 
+    def _stream(self) -> int:
+        import torch
+        return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+
     def _retire(self, b: int, stream) -> None:
         """Frame in buffer b: its gather has completed (stream-level wait); rank 0 assembles it."""
         self._pending[b].wait()
@@ -113,10 +121,9 @@ class TiledFrame:
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble.  Returns the frame tensor on rank 0
         (pipelined: the frame of the PREVIOUS step; call flush() after the last one)."""
-        import torch
         import torch.distributed as dist
 
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._stream()
         if self.world == 1 and not self._rehearse:
             self.ctx.render_device(self.params, self.frame.data_ptr(), self.frame.numel(), stream)
             return self.frame
@@ -143,9 +150,7 @@ class TiledFrame:
 
     def flush(self):
         """Complete the frames still in flight (pipelined mode); older first."""
-        import torch
-
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._stream()
         if self.pipelined:
             for b in ((self._k & 1), (self._k & 1) ^ 1):
                 if self._pending[b] is not None:
