@@ -821,8 +821,8 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.wave_iterations = h[mirt::kCntWaveIters];
         c->stats.grid_cells = h[mirt::kCntCells];
         c->stats.grid_wave_cells = h[mirt::kCntWaveCells];
-#ifdef MIRT_STAMP
-        c->stats.scatter[0] = h[12]; c->stats.scatter[1] = h[13]; c->stats.scatter[2] = h[14]; c->stats.sky_misses = h[15];
+#ifdef MIRT_PROBE_UNIFORM_NEXT
+        c->stats.grid_cells = h[14]; c->stats.grid_wave_cells = h[15]; c->stats.scatter[4] = h[12]; c->stats.roots = h[13];
 #endif
         c->stats_counted = false;
     }

@@ -124,13 +124,14 @@ struct SinCos { float s, c; };
 
 // sin & cos together: nearest-integer quadrant by the magic-number trick, three-part pi/2
 // reduction (three fmas), two degree-3 polynomials in r*r, quadrant fix-up.
-MIRT_DEV SinCos sincos_(float x)
+template <bool CLAMP>
+MIRT_DEV SinCos sincos_impl(float x)
 {
     constexpr float kSin[4] = { -0x1.5555560000000p-3f, 0x1.11110e0000000p-7f, -0x1.a013a80000000p-13f, 0x1.6dbe080000000p-19f };
     constexpr float kCos[4] = { 0x1.5555560000000p-5f, -0x1.6c16c00000000p-10f, 0x1.a015c80000000p-16f, -0x1.2524f20000000p-22f };
     constexpr float kTwoOverPi = 0.63661975f, kMagic = 12582912.0f;
     constexpr float kHi = 1.5703125f, kMd = 4.837512969970703125e-4f, kLo = 7.54978995489188216e-8f;
-    x = (abs_(x) <= 1048576.0f) ? x : 0.0f;              // outside the reduction domain / NaN -> 0
+    if constexpr (CLAMP) x = (abs_(x) <= 1048576.0f) ? x : 0.0f;   // outside the reduction domain / NaN -> 0
     const float kf = (x * kTwoOverPi + kMagic) - kMagic;
     const int q = (int)kf;
     float r = fma_(-kf, kHi, x);
@@ -147,6 +148,10 @@ MIRT_DEV SinCos sincos_(float x)
     o.c = ((q + 1) & 2) ? -c0 : c0;
     return o;
 }
+MIRT_DEV SinCos sincos_(float x) { return sincos_impl<true>(x); }
+// sincos_ for arguments the caller knows to be finite with |x| <= 2^20 (a variate times pi or 2 pi): the domain
+// clamp never acts there, so leaving it out gives the same bits.
+MIRT_DEV SinCos sincos_small(float x) { return sincos_impl<false>(x); }
 
 // Sign of sin(x) in {-1, 0, +1}: the argument reduction of sincos_ without the polynomials.
 // For |r| <= pi/4 cos(r) > 0 and sin(r) has the sign of r (zero iff r == 0).
@@ -163,6 +168,33 @@ MIRT_DEV int sin_sign(float x)
     const int sr = (r > 0.0f) - (r < 0.0f);
     const int base = (q & 1) ? 1 : sr;
     return (q & 2) ? -base : base;
+}
+
+// The reduction of sin_sign as bits, for products of sines: returns z = (bits(r) << 1) | (q & 1), which is 0 exactly
+// when sin is 0 (q even and r == +-0), and sets `neg` bit 0 to "sin < 0" (meaningless when sin is 0).
+MIRT_DEV uint32_t sin_sign_bits(float x, uint32_t& neg)
+{
+    constexpr float kTwoOverPi = 0.63661975f, kMagic = 12582912.0f;
+    constexpr float kHi = 1.5703125f, kMd = 4.837512969970703125e-4f, kLo = 7.54978995489188216e-8f;
+    x = (abs_(x) <= 1048576.0f) ? x : 0.0f;
+    const float kf = (x * kTwoOverPi + kMagic) - kMagic;
+    const uint32_t q = (uint32_t)(int)kf;
+    float r = fma_(-kf, kHi, x);
+    r = fma_(-kf, kMd, r);
+    r = fma_(-kf, kLo, r);
+    const uint32_t br = bits(r);
+    // q odd: |sin| = cos(r) > 0, sign + ; q even: the sign of r.  Then q & 2 negates.
+    neg = (((br >> 31) & ~q) ^ (q >> 1));
+    return (br << 1) | (q & 1u);
+}
+
+// sin(a) sin(b) sin(c) < 0, decided exactly as sin_sign(a) * sin_sign(b) * sin_sign(c) < 0
+MIRT_DEV bool sin_product_negative(float a, float b, float c)
+{
+    uint32_t n0, n1, n2;
+    const uint32_t z0 = sin_sign_bits(a, n0), z1 = sin_sign_bits(b, n1), z2 = sin_sign_bits(c, n2);
+    const uint32_t zmin = (z0 < z1) ? ((z0 < z2) ? z0 : z2) : ((z1 < z2) ? z1 : z2);      // v_min3_u32
+    return (((n0 ^ n1 ^ n2) & 1u) != 0u) && (zmin != 0u);
 }
 
 MIRT_DEV float asin_core(float x, float z)
@@ -239,6 +271,32 @@ MIRT_DEV float exp2_(float y)
     const float s2 = from_bits((uint32_t)(n2 + 127) << 23);
     const float r = (p * s1) * s2;
     return hi ? __builtin_inff() : (lo ? 0.0f : r);
+}
+
+// pow_pos(x, y) for 2^-32 <= x <= 1 (a non-zero uniform variate; 0 gives 0) and 0 < y <= 1: the same bits as
+// pow_pos with the branches that cannot act removed -- x is never subnormal (no 2^24 rescale), y * log2(x) lies in
+// [-32, 0] (no overflow / underflow clamps), and the two exact power-of-two scalings of exp2_ collapse into ONE
+// exact scaling (v_ldexp_f32) because p * 2^n with n >= -32 cannot round.
+MIRT_DEV float pow_unit(float x, float y)
+{
+    constexpr float kLog2[10] = { 0x1.7154760000000p+0f, -0x1.7154700000000p-1f, 0x1.ec70aa0000000p-2f, -0x1.715a700000000p-2f, 0x1.277a520000000p-2f, -0x1.eab7aa0000000p-3f, 0x1.a38c680000000p-3f, -0x1.87f6a20000000p-3f, 0x1.7a63a00000000p-3f, -0x1.b84fb60000000p-4f };
+    constexpr float kExp2[7] = { 0x1.62e4300000000p-1f, 0x1.ebfbe00000000p-3f, 0x1.c6b08e0000000p-5f, 0x1.3b2a1c0000000p-7f, 0x1.5d879e0000000p-10f, 0x1.4440000000000p-13f, 0x1.00a5800000000p-16f };
+    constexpr float kMagic = 12582912.0f;
+    const bool pos = x > 0.0f;
+    const uint32_t u = bits(pos ? x : 1.0f);
+    const int e0 = (int)(u >> 23) - 127;
+    const uint32_t m0 = (u & 0x007fffffu) | 0x3f800000u;
+    const bool big = m0 >= 0x3fb504f3u;
+    const uint32_t m = big ? (m0 - 0x00800000u) : m0;
+    const int e = big ? (e0 + 1) : e0;
+    const float f = from_bits(m) - 1.0f;
+    const float lg = fma_(f, horner(kLog2, f), (float)e);
+    const float yy = y * lg;
+    const float nf = (yy + kMagic) - kMagic;
+    const float g = yy - nf;
+    const float pw = fma_(g, horner(kExp2, g), 1.0f);
+    const float r = __builtin_amdgcn_ldexpf(pw, (int)nf);
+    return pos ? r : 0.0f;
 }
 
 MIRT_DEV float pow_pos(float x, float y)

@@ -347,6 +347,16 @@ struct Rng {
         state = (word >> 22) ^ word;
         return (float)state * 0x1p-32f;
     }
+    // c * next() for a constant c in one multiplication: next() = f * 2^-32 is exact (a power-of-two scaling of the
+    // converted integer), so c * (f * 2^-32) and (c * 2^-32) * f round the same real number, c * f * 2^-32, once
+    // each -- identical bits as long as nothing underflows (|c| >= 2^-60 is ample).  The caller passes c * 2^-32.
+    MIRT_DEV float next_scaled(float c_times_2m32)
+    {
+        const uint32_t old = state + 747796405u + 2891336453u;
+        const uint32_t word = ((old >> ((old >> 28) + 4u)) ^ old) * 277803737u;
+        state = (word >> 22) ^ word;
+        return (float)state * c_times_2m32;
+    }
 };
 
 // camera constants hoisted into registers once per thread
@@ -379,7 +389,7 @@ MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x
     const float u = ((float)x + rng.next()) * C.inv_w;
     const float v = 1.0f - ((float)y + rng.next()) * C.inv_h;
     const float lr = sqrt_unit(rng.next());
-    const SinCos la = sincos_(kTwoPi * rng.next());
+    const SinCos la = sincos_small(rng.next_scaled(kTwoPi * 0x1p-32f));
     const float lpx = C.lens_radius * (lr * la.c);
     const float lpy = C.lens_radius * (lr * la.s);
     ro = C.eye + fma3(lpy, C.cam_v, lpx * C.cam_u);
@@ -403,9 +413,7 @@ MIRT_DEV void hit_sphere(const float4 s4, uint32_t i, f3 ro, f3 rd, float a, flo
         const float t1 = (-b + sq) * inv_a;
         const bool ok0 = (t0 < closest) && (t0 > kMinT);    // first root, else second (wgsl:415-425), branch-free
         const bool ok1 = (t1 < closest) && (t1 > kMinT);
-#ifndef MIRT_STAMP
         work.add(kCntRoots, ok0 ? 1u : 2u);
-#endif
         const float t = ok0 ? t0 : t1;
         const bool ok = ok0 || ok1;
         closest = ok ? t : closest;
@@ -423,6 +431,18 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
     int best = -1;
     if (alive) { work.add(kCntRays); work.add(kCntTests, n_spheres); }
     const float4* sph = reinterpret_cast<const float4*>(S.spheres);     // {centre, radius^2} is the first half of a PreparedSphere
+    // The reference's own scenes hold 2-6 spheres: lists of up to four are straight-line code (all reads issued
+    // together, no loop bookkeeping) behind one wave-uniform switch; measured -1.5 % on config 3 (tools/ab_libs.py).
+    if (n_spheres >= 1u && n_spheres <= 4u) {
+        const float4 s0 = sph[0];
+        const float4 s1 = sph[n_spheres > 1u ? 2 : 0], s2 = sph[n_spheres > 2u ? 4 : 0], s3 = sph[n_spheres > 3u ? 6 : 0];
+        hit_sphere<COUNT>(s0, 0, ro, rd, a, inv_a, alive, closest, best, work);
+        if (n_spheres > 1u) hit_sphere<COUNT>(s1, 1, ro, rd, a, inv_a, alive, closest, best, work);
+        if (n_spheres > 2u) hit_sphere<COUNT>(s2, 2, ro, rd, a, inv_a, alive, closest, best, work);
+        if (n_spheres > 3u) hit_sphere<COUNT>(s3, 3, ro, rd, a, inv_a, alive, closest, best, work);
+        closest_out = closest;
+        return best;
+    }
     uint32_t i = 0;
     for (; i + 3 <= n_spheres; i += 3) {                                 // three LDS reads in flight per round trip
         const float4 s0 = sph[2 * i], s1 = sph[2 * i + 2], s2 = sph[2 * i + 4];
@@ -577,10 +597,10 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 
 MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
 {
-    const float r = pow_pos(rng.next(), 0.33333f);
-    const float theta = kPi * rng.next();
-    const float phi = kTwoPi * rng.next();
-    const SinCos t = sincos_(theta), p = sincos_(phi);
+    const float r = pow_unit(rng.next(), 0.33333f);
+    const float theta = rng.next_scaled(kPi * 0x1p-32f);
+    const float phi = rng.next_scaled(kTwoPi * 0x1p-32f);
+    const SinCos t = sincos_small(theta), p = sincos_small(phi);
     const float rs = r * t.s;
     return mk(rs * p.c, rs * p.s, r * t.c);
 }
@@ -622,11 +642,11 @@ MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 
 // scatterLambertian (wgsl:204-242): cosine-weighted direction around n through the Pixar ONB
 MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, Rng& rng, f3& dir, f3& atten)
 {
-    const float r1 = rng.next();
+    const float phi = rng.next_scaled(kTwoPi * 0x1p-32f);      // 2 pi r1 (r1 is used nowhere else)
     const float r2 = rng.next();
     const float sqrt_r2 = sqrt_unit(r2);
     const float z = sqrt_unit(1.0f - r2);
-    const SinCos sc = sincos_(kTwoPi * r1);
+    const SinCos sc = sincos_small(phi);
     const float lx = sc.c * sqrt_r2;
     const float ly = sc.s * sqrt_r2;
     const float sg = (n.z >= 0.0f) ? 1.0f : -1.0f;
@@ -645,7 +665,11 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
         asm volatile("; scatter_lambertian: grazing direction" ::);
         if (grazing) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
     }
-    atten = kk * albedo_at(A, m, k, n);
+    atten = albedo_at(A, m, k, n);
+    if (__builtin_expect(__ballot(grazing) != 0ull, 0)) {      // kk == 1.0f elsewhere, and 1.0f * x == x
+        asm volatile("; scatter_lambertian: grazing attenuation" ::);
+        atten = kk * atten;
+    }
     dir = wi;
 }
 
@@ -689,8 +713,8 @@ MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng
 
 MIRT_DEV void shade_checkerboard(const RenderArgs& A, const PreparedMaterial* m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att)
 {   // scatterCheckerboard wgsl:300-307: sign of sin(5x)sin(5y)sin(5z) from the signs of the factors
-    const int sines = sin_sign(5.0f * hp.x) * sin_sign(5.0f * hp.y) * sin_sign(5.0f * hp.z);
-    scatter_lambertian(A, m, (sines < 0) ? 0 : 1, hn, rng, ndir, att);
+    const bool negative = sin_product_negative(5.0f * hp.x, 5.0f * hp.y, 5.0f * hp.z);
+    scatter_lambertian(A, m, negative ? 0 : 1, hn, rng, ndir, att);
 }
 
 MIRT_DEV void shade_missing(f3 hn, Rng& rng, f3& ndir, f3& att)
@@ -737,8 +761,7 @@ MIRT_DEV f3 sky_color(const SceneLds& S, f3 d)
 MIRT_DEV uint32_t to_fixed(float c)          // 2^-20 units, clamped to [0, 4096)
 {
     const float p = (c > 0.0f) ? c : 0.0f;                  // NaN and negatives -> 0 (select, no branch)
-    float s = p * 1048576.0f;
-    s = (s >= 4294967040.0f) ? 4294967040.0f : s;
+    const float s = __builtin_fminf(p * 1048576.0f, 4294967040.0f);    // p is never NaN here: one v_min_f32
     return (uint32_t)s;
 }
 
@@ -921,6 +944,12 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
 // NQ = OP_GEN.
 constexpr uint32_t RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2, RT_CHECKER = 3;
 constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
+// pool kernel: a step whose paths all move on to one routine continues with it directly (no store / push / pop /
+// gather) if it holds at least this many paths; 65 switches fast-forwarding off (experiment builds)
+#ifndef MIRT_FF_MIN
+#define MIRT_FF_MIN 64
+#endif
+constexpr uint32_t kFastForwardMin = MIRT_FF_MIN;
 
 // ------------------------------------------------------------------------------------------
 // render_pt_pool — wave-private path pool: every wave-instruction runs ONE shading routine
@@ -1008,50 +1037,60 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         for (uint32_t k = 0; k < kNumOps; ++k) tail[k] = (k == OP_GEN) ? SLOTS : 0u;
         uint32_t next_item = 0;
 
-        for (;;) {
-#ifdef MIRT_STAMP
-            unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-            if constexpr (COUNT) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory"); }
-#endif
-            // ---- pick the deepest queue: max over keys depth << 3 | (7 - op); ties go to the lower op ----
-            uint32_t key = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kNumOps; ++k) {
-                const uint32_t kk = (tail[k] << 3) | (7u - k);
-                key = (kk > key) ? kk : key;
-            }
-            const uint32_t depth = key >> 3;
-            if (depth == 0) break;                         // every queue empty: strip finished
-            const uint32_t my_k = 7u - (key & 7u);
-            const uint32_t my_n = (depth > 64u) ? 64u : depth;
-            const uint32_t my_begin = depth - my_n;        // the top my_n entries
-#pragma unroll
-            for (uint32_t k = 0; k < kNumOps; ++k) {
-                tail[k] -= (my_k == k) ? my_n : 0u;
-            }
+        // Loop-carried path state of the lanes (registers).  A normal step loads it from the wave's pool (pick a queue,
+        // pop slot ids, gather); a FAST-FORWARD step inherits it from the step before: when every lane of a step moves
+        // on to the SAME routine (coherent primary rays all hitting the ground, sky pixels going straight back to OP_GEN:
+        // 43 % of all steps on config 3), storing the paths, pushing, picking, popping and gathering them again would
+        // only move the same 64 paths through LDS, so the wave runs that routine on them right away.  The order in
+        // which paths are served is free (exact integer accumulation), so the image cannot change.
+        bool ff = false;                                   // wave-uniform
+        uint32_t my_k = 0, my_n = 0;                       // wave-uniform: routine of this step, number of paths
+        uint32_t slot = 0, pix = 0, bounce = 0, missf = 0;
+        int best = 0;
+        f3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), thr = mk(0, 0, 0);
+        Rng rng;
+        rng.state = 0;
 
-            // ---- pop + gather ----
+        for (;;) {
+            if (!ff) {
+                // ---- pick the deepest queue: max over keys depth << 3 | (7 - op); ties go to the lower op ----
+                uint32_t key = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kNumOps; ++k) {
+                    const uint32_t kk = (tail[k] << 3) | (7u - k);
+                    key = (kk > key) ? kk : key;
+                }
+                const uint32_t depth = key >> 3;
+                if (depth == 0) break;                     // every queue empty: strip finished
+                my_k = 7u - (key & 7u);
+                my_n = (depth > 64u) ? 64u : depth;
+                const uint32_t my_begin = depth - my_n;    // the top my_n entries
+#pragma unroll
+                for (uint32_t k = 0; k < kNumOps; ++k) {
+                    tail[k] -= (my_k == k) ? my_n : 0u;
+                }
+
+                // ---- pop + gather ----
+                const bool has0 = lane < my_n;
+                slot = has0 ? (uint32_t)L_ring[my_k * RING + my_begin + lane] : 0u;
+                const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
+                const uint32_t fl = q0.w;
+                ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
+                rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
+                best = has0 ? (int)(fl & 0xfffu) : 0;
+                thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
+                rng.state = q1.w;
+                pix = (fl >> 12) & 0xfu;
+                bounce = (fl >> 16) & 0xffu;
+                missf = (fl >> 24) & 1u;
+            }
             const bool has = lane < my_n;
-            const uint32_t slot = has ? (uint32_t)L_ring[my_k * RING + my_begin + lane] : 0u;
-            uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
-#ifdef MIRT_STAMP
-            if constexpr (COUNT) { asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st1) :: "memory"); asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.x)); }
-#endif
-            const uint32_t fl = q0.w;
-            f3 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
-            f3 rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
-            const int best = has ? (int)(fl & 0xfffu) : 0;
-            f3 thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
-            Rng rng;
-            rng.state = q1.w;
-            uint32_t pix = (fl >> 12) & 0xfu;
-            uint32_t bounce = (fl >> 16) & 0xffu;
             bool alive = has;
             if constexpr (COUNT) { if (lane == 0) work.add(kCntWaveIters); }
 
             if (my_k == OP_GEN) {
                 // finish the previous path of this slot ...
-                if (has && ((fl >> 24) & 1u)) {
+                if (has && missf) {
                     work.add(kCntSky);
                     const f3 c = sky_color<HOSEK>(S, rd);
                     atomicAdd(&L_acc[pix * 3 + 0], (unsigned long long)to_fixed(thr.x * c.x));
@@ -1109,12 +1148,41 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 bounce += 1;
             }
 
-#ifdef MIRT_STAMP
-            if constexpr (COUNT) { asm volatile("" : "+v"(rd.x), "+v"(ro.x), "+v"(thr.x), "+v"(rng.state)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st2) :: "memory"); asm volatile("" : "+v"(rd.x), "+v"(ro.x), "+v"(thr.x), "+v"(rng.state)); }
+#if defined(MIRT_PROBE_VALU) || defined(MIRT_PROBE_LDS) || defined(MIRT_PROBE_SALU) || defined(MIRT_PROBE_VALU_DEP)
+            // Sensitivity probes (experiment builds only, tools/ab_libs.py): extra instructions of ONE class per step,
+            // independent of the step's data, to measure what one more instruction of that class costs.
+            {
+                float pv0 = thr.x, pv1 = thr.y, pv2 = thr.z;
+#ifdef MIRT_PROBE_VALU          // 32 independent full-rate VALU ops
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %2, 1.0, %2\n v_mul_f32 %3, %0, %1" : "+v"(pv0), "+v"(pv1), "+v"(pv2), "=v"(pv0) : );
+#endif
+#ifdef MIRT_PROBE_VALU_DEP      // 32 VALU ops in ONE dependent chain
+#pragma unroll
+                for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pv0));
+#endif
+#ifdef MIRT_PROBE_LDS           // 4 broadcast ds_read_b128 of the scene (conflict-free)
+                {
+                    uint4 t0, t1, t2, t3;
+                    const uint32_t a0 = 0;
+                    asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
+                                 : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : "v"(a0) : "memory");
+                    pv1 = from_bits(t0.x ^ t1.x ^ t2.x ^ t3.x);
+                }
+#endif
+#ifdef MIRT_PROBE_SALU          // 32 SALU ops
+                {
+                    uint32_t sv = 1u;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sv) : : "scc");
+                    if (sv == 0xdeadbeefu) pv2 = 0.0f;
+                }
+#endif
+                asm volatile("" :: "v"(pv0), "v"(pv1), "v"(pv2));
+            }
 #endif
             // common tail: bounce limit (wgsl:130), nearest hit, classification
-            uint32_t new_op = OP_NONE;
-            uint32_t miss = 0;
             const bool trace = alive && bounce < A.num_bounces;
             if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
             float closest;
@@ -1123,20 +1191,41 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             else nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
             const bool hit = trace && nb >= 0;
             if (hit) work.add(kCntHits);
-            miss = (trace && nb < 0) ? 1u : 0u;            // left the scene: OP_GEN adds throughput x sky
-#ifdef MIRT_STAMP
-            if constexpr (COUNT) { asm volatile("" : "+v"(new_op), "+v"(closest)); asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st3) :: "memory"); asm volatile("" : "+v"(new_op), "+v"(closest)); }
-#endif
+            const uint32_t miss = (trace && nb < 0) ? 1u : 0u;        // left the scene: OP_GEN adds throughput x sky
+            const f3 hp = fma3(closest, rd, ro);           // rayPointAtParameter (wgsl:442-444); unused after a miss
+            // next routine, branch-free: the queue of a sphere's routine is kept with the sphere.  OP_GEN also when
+            // the bounce limit ended the path.
+            const uint32_t new_op = alive ? (hit ? S.spheres[hit ? nb : 0].op : OP_GEN) : OP_NONE;
+
+            // ---- fast-forward: all paths of this step wait for ONE routine -> run it on them now ----
+            if constexpr (kFastForwardMin <= 64u) {
+                const uint32_t k2 = __builtin_amdgcn_readfirstlane(new_op);      // lane 0 always holds a path (my_n >= 1)
+                if (k2 != OP_NONE && my_n >= kFastForwardMin && __ballot(has && new_op != k2) == 0ull) {
+                    ff = true;
+                    my_k = k2;
+                    ro = hp;
+                    best = nb < 0 ? 0 : nb;
+                    missf = miss;
+                    continue;
+                }
+                ff = false;
+            }
+
             if (has) {
-                const f3 hp = fma3(closest, rd, ro);       // rayPointAtParameter (wgsl:442-444); unused after a miss
                 const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24);
                 L_state[slot * 3 + 0] = make_uint4(bits(hp.x), bits(hp.y), bits(hp.z), packed);
                 L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
                 L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), 0u);
             }
-            // next queue, branch-free (after the state is stored: fewer live registers): the queue of a sphere's
-            // routine is kept with the sphere.  OP_GEN also when the bounce limit ended the path.
-            new_op = alive ? (hit ? S.spheres[hit ? nb : 0].op : OP_GEN) : OP_NONE;
+#ifdef MIRT_PROBE_UNIFORM_NEXT   // experiment: how often do all lanes of a step move on to ONE routine?
+            if constexpr (COUNT) {
+                const unsigned long long act = __ballot(new_op != OP_NONE);
+                const uint32_t first_op = __builtin_amdgcn_readfirstlane(new_op);
+                const bool uniform = act != 0ull && __ballot(new_op == first_op) == act && (act & 1ull);
+                if (lane == 0) { work.add(14, uniform ? 1u : 0u); work.add(15, (uniform && __popcll(act) >= 56) ? 1u : 0u);
+                                 work.add(12, (uniform && first_op == OP_GEN) ? 1u : 0u); work.add(13, __popcll(act) >= 56 ? 1u : 0u); }
+            }
+#endif
             // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
@@ -1144,13 +1233,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 if (new_op == k) L_ring[k * RING + tail[k] + (uint32_t)__popcll(mk_ & lt_mask)] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
             }
-#ifdef MIRT_STAMP
-            if constexpr (COUNT) {
-                unsigned long long st4; asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(st4) :: "memory");
-                if (lane == 0) { work.add(12, (uint32_t)(st1 - st0)); work.add(my_k == OP_GEN ? 13 : 14, (uint32_t)(st2 - st1)); work.add(15, (uint32_t)(st3 - st2));
-                                 work.add(kCntScatter4, (uint32_t)(st4 - st3)); work.add(my_k == OP_GEN ? kCntScatter3 : kCntRoots, 1); }
-            }
-#endif
         }
 
         // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
