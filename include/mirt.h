@@ -143,7 +143,12 @@ enum {
     /* With MIRT_FLAG_COUNT_WORK on a many-sphere scene: count the work of the grid build that renders such
      * scenes in production (sphere_tests = tests a lane really performs, grid_cells) instead of falling back to
      * the reference's flat scan, whose counters are the oracle's. */
-    MIRT_FLAG_COUNT_GRID     = 1u << 7
+    MIRT_FLAG_COUNT_GRID     = 1u << 7,
+    /* OPT-IN fast-math build of the path-traced kernels: hardware v_rcp / v_rsq / v_sqrt / v_sin / v_cos / v_exp /
+     * v_log (about 1 ulp) and contraction instead of the bit-exact arithmetic.  Same RNG streams and exact integer
+     * accumulation, so the image is deterministic, but pixels may differ from the default build by a few units in
+     * the last place: NO parity claim holds with this flag.  Ignored by counting launches and in parity mode. */
+    MIRT_FLAG_FAST_MATH      = 1u << 8
 };
 
 /* What one render call computes.  The image is `width x height`; this call renders the rows

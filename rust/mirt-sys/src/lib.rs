@@ -102,6 +102,7 @@ pub const MIRT_FLAG_KERNEL_STRIP: u32 = 1 << 4;
 pub const MIRT_FLAG_KERNEL_POOL: u32 = 1 << 5;
 pub const MIRT_FLAG_NO_GRID: u32 = 1 << 6;
 pub const MIRT_FLAG_COUNT_GRID: u32 = 1 << 7;
+pub const MIRT_FLAG_FAST_MATH: u32 = 1 << 8;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

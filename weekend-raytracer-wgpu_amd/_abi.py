@@ -18,6 +18,7 @@ MIRT_FLAG_KERNEL_STRIP = 1 << 4
 MIRT_FLAG_KERNEL_POOL = 1 << 5
 MIRT_FLAG_NO_GRID = 1 << 6
 MIRT_FLAG_COUNT_GRID = 1 << 7
+MIRT_FLAG_FAST_MATH = 1 << 8
 
 MIRT_OK = 0
 STATUS = {

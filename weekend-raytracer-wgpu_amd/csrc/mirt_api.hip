@@ -19,6 +19,9 @@
 #include "../../include/mirt.h"
 #include "mirt_kernels.h"
 
+namespace kx = mirt::exact_build;     // the kernels of the bit-exact build (default)
+namespace kf = mirt::fast_build;      // MIRT_FLAG_FAST_MATH: the same kernels with hardware transcendentals
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -188,7 +191,7 @@ struct Tuning {
 Tuning read_tuning()
 {
     Tuning t;
-    if (const char* e = std::getenv("MIRT_POOL_CONFIG")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && (uint32_t)v < mirt::pool_config_count()) t.pool_config = (int)v; }
+    if (const char* e = std::getenv("MIRT_POOL_CONFIG")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && (uint32_t)v < kx::pool_config_count()) t.pool_config = (int)v; }
     if (const char* e = std::getenv("MIRT_POOL_GRID")) t.pool_grid = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_STRIP_MODE")) t.fixed_strips = e[0] == '1';
     if (const char* e = std::getenv("MIRT_GSS_MINW")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1 && v <= 16) t.gss_min_width = v; }
@@ -443,10 +446,10 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_texels && !s->texels) return fail(MIRT_ERR_NULL_POINTER, "texels is null");
     // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
     // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
-    const bool fits_flat = mirt::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
+    const bool fits_flat = kx::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
     const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell);
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
-                           mirt::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;
+                           kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;
     if (!fits_flat && !fits_grid)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
                     s->n_materials, mirt::kMaxLdsBytes);
@@ -609,13 +612,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool hosek = p->mode == MIRT_MODE_PT && (p->flags & MIRT_FLAG_SKY_HOSEK);
 
     const bool pt = p->mode == MIRT_MODE_PT;
-    const size_t scene_lds = mirt::scene_lds_bytes(c->n_spheres, c->n_mats, pt, hosek);
+    const size_t scene_lds = kx::scene_lds_bytes(c->n_spheres, c->n_mats, pt, hosek);
     // kernel choice (path-traced mode): the pooled kernel needs enough samples per tile to keep
     // its path pool full, 8-bit bounce counters and room for the pool beside the scene in LDS
     const Tuning& tune = c->tuning;
     const uint32_t pool_cfg = tune.pool_config >= 0 ? (uint32_t)tune.pool_config : mirt::kDefaultPoolConfig;
-    const uint32_t pool_nq = mirt::pool_scatter_queues(c->n_shading_routines, count);
-    const mirt::PoolConfig pc = mirt::pool_config(pool_cfg, pool_nq);
+    const uint32_t pool_nq = kx::pool_scatter_queues(c->n_shading_routines, count);
+    const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when paths diverge over >= 2 scatter routines,
     // a strip holds enough samples to keep the pool full, and the pools still leave >= 16 waves
     // per CU resident beside the scene tables (measured: 1 sphere 0.9x, 3 spheres 1.4x, 5 spheres
@@ -628,7 +631,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block || !c->fits_flat) pool = false;
     // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
-    const size_t scene_lds_g = mirt::scene_lds_bytes_grid(c->n_spheres, hosek);
+    const size_t scene_lds_g = kx::scene_lds_bytes_grid(c->n_spheres, hosek);
     // counting launches keep the reference's flat scan (their counters are then the reference's) unless
     // MIRT_FLAG_COUNT_GRID asks for the work of the grid build that renders the scene in production
     const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
@@ -732,17 +735,21 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
+    // the opt-in fast-math build of the path-traced kernels; counting launches always run the exact build
+    const bool fast = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
     const char* tf[2] = { "false", "true" };
+    char kname[112] = "";
     if (p->mode == MIRT_MODE_PARITY) {
-        HIP_TRY(mirt::launch_parity(a, blocks, count, stream));
+        HIP_TRY(kx::launch_parity(a, blocks, count, stream));
         snprintf(c->last_kernel, sizeof c->last_kernel, "render_parity_kernel<%s>", tf[count]);
     } else if (pool) {
-        HIP_TRY(mirt::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
-        mirt::pool_kernel_name(a, pool_cfg, count, pool_nq, c->last_kernel, sizeof c->last_kernel);
+        HIP_TRY(fast ? kf::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream) : kx::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
+        kx::pool_kernel_name(a, pool_cfg, count, pool_nq, kname, sizeof kname);
+        snprintf(c->last_kernel, sizeof c->last_kernel, "%s%s", fast ? "fast_build::" : "", kname);
     } else {
-        HIP_TRY(mirt::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
-        snprintf(c->last_kernel, sizeof c->last_kernel, "render_pt_strip_kernel<%s,%s,%s,%s>", tf[count], tf[hosek], tf[use_grid],
-                 tf[by_pixel && !count]);
+        HIP_TRY(fast ? kf::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream) : kx::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
+        snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
+                 tf[use_grid], tf[by_pixel && !count]);
     }
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     if (d_accum) {                                   // resolve/read must see these sums whatever stream they were added on
@@ -875,7 +882,7 @@ int mirt_ctx_accum_resolve(MirtContext* c, const MirtParams* p, uint8_t* out, si
     int rc;
     if ((rc = ensure_capacity(&c->d_out, &c->cap_out, (size_t)c->accum_pixels)) != MIRT_OK) return rc;
     if (c->accum_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_accum, 0));   // adds may sit on a caller stream
-    HIP_TRY(mirt::launch_resolve(c->d_accum, c->d_out, c->accum_pixels, c->accum_samples, p->flags, c->stream));
+    HIP_TRY(kx::launch_resolve(c->d_accum, c->d_out, c->accum_pixels, c->accum_samples, p->flags, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)c->accum_pixels * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MIRT_OK;
@@ -899,7 +906,7 @@ int mirt_ctx_selftest_math(MirtContext* c, uint64_t out[2])
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = mirt_ctx_synchronize(c); if (rc != MIRT_OK) return rc; }    // borrows counter block 0
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(mirt::launch_selftest_math(c->d_counters, c->stream));
+    HIP_TRY(kx::launch_selftest_math(c->d_counters, c->stream));
     unsigned long long h[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -948,7 +955,7 @@ int mirt_ctx_deinterleave_device(MirtContext* c, const MirtParams* p, const void
     mirt::DeinterleaveArgs d{};
     d.parts = (const uint32_t*)d_parts; d.out = (uint32_t*)d_out; d.part_stride_px = part_stride / 4;
     d.width = p->width; d.band_rows = band; d.tile_rows = p->tile_rows; d.n_parts = p->n_parts;
-    HIP_TRY(mirt::launch_deinterleave(d, hip_stream ? (hipStream_t)hip_stream : c->stream));
+    HIP_TRY(kx::launch_deinterleave(d, hip_stream ? (hipStream_t)hip_stream : c->stream));
     return MIRT_OK;
 }
 

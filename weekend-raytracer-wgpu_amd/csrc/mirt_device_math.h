@@ -15,7 +15,17 @@
 
 #define MIRT_DEV __device__ __forceinline__
 
+// The kernels exist in two builds of the same source (mirt_kernels.hip is compiled twice):
+//   exact_build  the default and the only one parity is claimed for: the bit-exact arithmetic described above;
+//   fast_build   opt-in (MIRT_FLAG_FAST_MATH): hardware v_rcp / v_rsq / v_sqrt / v_sin / v_cos / v_exp / v_log
+//                (about 1 ulp), contraction allowed, approximate division.  Same RNG streams, same integer
+//                accumulation; pixels may differ from the exact build by a few units in the last place.
+#ifndef MIRT_KNS
+#define MIRT_KNS exact_build
+#endif
+
 namespace mirt {
+namespace MIRT_KNS {
 
 // constants exactly as the reference shader spells them (raytracer.wgsl:1-8)
 constexpr float kEpsilon  = 0.001f;
@@ -36,6 +46,13 @@ MIRT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c);
 MIRT_DEV float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
 MIRT_DEV float rcp_ieee(float a) { return 1.0f / a; }
 
+#ifdef MIRT_FAST_MATH
+MIRT_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+MIRT_DEV float sqrt_unit(float x) { return __builtin_amdgcn_sqrtf(x); }
+MIRT_DEV float sqrt_unit_where(float x, bool) { return __builtin_amdgcn_sqrtf(x); }
+MIRT_DEV float rcp_in_range(float x) { return __builtin_amdgcn_rcpf(x); }
+MIRT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
 MIRT_DEV float sqrt_(float x)
 {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -106,6 +123,7 @@ MIRT_DEV float rcp_(float x)           // == 1.0f / x bit for bit
     }
     return y;
 }
+#endif  // MIRT_FAST_MATH
 MIRT_DEV float abs_(float a) { return __builtin_fabsf(a); }
 MIRT_DEV uint32_t bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 MIRT_DEV float from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -124,6 +142,19 @@ struct SinCos { float s, c; };
 
 // sin & cos together: nearest-integer quadrant by the magic-number trick, three-part pi/2
 // reduction (three fmas), two degree-3 polynomials in r*r, quadrant fix-up.
+#ifdef MIRT_FAST_MATH
+// v_sin_f32 / v_cos_f32 take their argument in revolutions and are specified for |x| <= 256 revolutions
+template <bool CLAMP>
+MIRT_DEV SinCos sincos_impl(float x)
+{
+    if constexpr (CLAMP) x = (abs_(x) <= 1024.0f) ? x : 0.0f;
+    const float turns = x * 0.15915494f;
+    SinCos o;
+    o.s = __builtin_amdgcn_sinf(turns);
+    o.c = __builtin_amdgcn_cosf(turns);
+    return o;
+}
+#else
 template <bool CLAMP>
 MIRT_DEV SinCos sincos_impl(float x)
 {
@@ -148,6 +179,7 @@ MIRT_DEV SinCos sincos_impl(float x)
     o.c = ((q + 1) & 2) ? -c0 : c0;
     return o;
 }
+#endif  // MIRT_FAST_MATH
 MIRT_DEV SinCos sincos_(float x) { return sincos_impl<true>(x); }
 // sincos_ for arguments the caller knows to be finite with |x| <= 2^20 (a variate times pi or 2 pi): the domain
 // clamp never acts there, so leaving it out gives the same bits.
@@ -237,6 +269,11 @@ MIRT_DEV float atan2_(float y, float x)
     return (mx > 0.0f) ? r : 0.0f;                         // branch-free: selects only
 }
 
+#ifdef MIRT_FAST_MATH
+MIRT_DEV float log2_(float x) { return __builtin_amdgcn_logf(x); }      // v_log_f32 = log2
+MIRT_DEV float exp2_(float y) { return __builtin_amdgcn_exp2f(y); }     // v_exp_f32 = 2^y
+MIRT_DEV float pow_unit(float x, float y) { return (x > 0.0f) ? exp2_(y * log2_(x)) : 0.0f; }
+#else
 // log2 of a finite positive float.
 MIRT_DEV float log2_(float x)
 {
@@ -298,6 +335,7 @@ MIRT_DEV float pow_unit(float x, float y)
     const float r = __builtin_amdgcn_ldexpf(pw, (int)nf);
     return pos ? r : 0.0f;
 }
+#endif  // MIRT_FAST_MATH
 
 MIRT_DEV float pow_pos(float x, float y)
 {
@@ -320,6 +358,9 @@ MIRT_DEV f3 fma3(float s, f3 a, f3 b) { return mk(fma_(s, a.x, b.x), fma_(s, a.y
 MIRT_DEV float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 // 1 / sqrt(x) as two correctly rounded steps, == rcp_(sqrt_(x)) bit for bit, behind ONE range check: for
 // 2^-100 <= x <= 2^100 the square root lies in [2^-50, 2^50], inside the reciprocal's fast range too.
+#ifdef MIRT_FAST_MATH
+MIRT_DEV float inv_sqrt_2step(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
 MIRT_DEV float inv_sqrt_2step(float x)
 {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -337,8 +378,10 @@ MIRT_DEV float inv_sqrt_2step(float x)
     }
     return r;
 }
+#endif  // MIRT_FAST_MATH
 MIRT_DEV f3 normalize(f3 a) { return inv_sqrt_2step(dot(a, a)) * a; }
 // parity-mode dot (nalgebra, no fusion): (a0*b0 + a1*b1) + a2*b2
 MIRT_DEV float dot_nofma(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
+}  // namespace MIRT_KNS
 }  // namespace mirt

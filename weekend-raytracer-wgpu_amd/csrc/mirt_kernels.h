@@ -114,10 +114,17 @@ struct DeinterleaveArgs {
     uint32_t        width, band_rows, tile_rows, n_parts;
 };
 
-// launchers (mirt_kernels.hip)
+// launchers (mirt_kernels.hip).  That file is compiled twice: namespace exact_build (the default, bit-exact arithmetic;
+// everything below) and namespace fast_build (mirt_kernels_fast.hip: MIRT_FLAG_FAST_MATH, hardware transcendentals;
+// path-traced launchers and the host helpers only).
+struct PoolConfig { uint32_t threads, slots, lds_bytes; };
+namespace fast_build {
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
+}
+namespace exact_build {
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
-struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
@@ -130,5 +137,6 @@ hipError_t launch_selftest_math(unsigned long long* d_mismatches, hipStream_t st
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream);
 size_t     scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek);
 size_t     scene_lds_bytes_grid(uint32_t n_spheres, bool hosek);
+}  // namespace exact_build
 
 }  // namespace mirt

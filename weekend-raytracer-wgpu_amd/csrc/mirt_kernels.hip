@@ -23,6 +23,7 @@
 #include "mirt_device_math.h"
 
 namespace mirt {
+namespace MIRT_KNS {
 
 // ------------------------------------------------------------------------------------------
 // shared helpers
@@ -175,6 +176,7 @@ struct PHit { f3 p, n; };
 // and `update_ray_hit_info` / `set_face_normal` (mod.rs:1217-1243, 1095-1110).
 // Returns the LAST sphere in list order with a root in [tmin, tmax]: `closest_hit` is reset to
 // `old_hit` = rec.t, which nobody ever writes (it stays f32::MAX).
+#ifndef MIRT_FAST_MATH       // parity mode exists in the exact build only
 struct PCount { uint32_t tests, roots, hits; };     // what ONE ray_hit_world_raw call costs the reference
 
 template <bool COUNT>
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
         work.flush(A.counters, lane);
     }
 }
+
+#endif  // !MIRT_FAST_MATH
 
 // ------------------------------------------------------------------------------------------
 // path-traced mode: building blocks shared by the strip and the pool kernel
@@ -1248,6 +1252,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     }
 }
 
+#ifndef MIRT_FAST_MATH       // self-test, resolve and de-interleave live in the exact build only
 // ------------------------------------------------------------------------------------------
 // self-test: the fast sqrt_/rcp_ against the IEEE expansions over ALL 2^32 binary32 patterns
 // ------------------------------------------------------------------------------------------
@@ -1318,6 +1323,8 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(DeinterleaveArgs D)
     }
 }
 
+#endif  // !MIRT_FAST_MATH
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -1346,20 +1353,27 @@ static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a,
     return hipGetLastError();
 }
 
+#ifndef MIRT_FAST_MATH
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
 {
     return count ? launch_with_lds(render_parity_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), a, stream)
                  : launch_with_lds(render_parity_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
+#endif
+
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const dim3 g(grid_blocks), b(kBlockThreads);
+#ifdef MIRT_FAST_MATH
+    if (count) return hipErrorInvalidValue;              // the counting builds exist in the exact build only
+#else
     if (count && use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, true>, g, b, a, stream)
                                         : launch_with_lds(render_pt_strip_kernel<true, false, true>, g, b, a, stream);
     if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
                             : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
+#endif
     if (by_pixel) {
         if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true, true>, g, b, a, stream)
                                    : launch_with_lds(render_pt_strip_kernel<false, false, true, true>, g, b, a, stream);
@@ -1376,8 +1390,12 @@ template <uint32_t T, uint32_t SL, uint32_t MW = 1>
 static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(T);
+#ifdef MIRT_FAST_MATH
+    if (count) return hipErrorInvalidValue;
+#else
     if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, false>, g, b, a, stream);
+#endif
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true>, g, b, a, stream)
@@ -1389,8 +1407,12 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(256);
+#ifdef MIRT_FAST_MATH
+    if (count) return hipErrorInvalidValue;
+#else
     if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, true, 5, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, false, 5, true>, g, b, a, stream);
+#endif
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 3, true>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 3, true>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 5, true>, g, b, a, stream)
@@ -1457,6 +1479,7 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
     snprintf(out, out_len, "render_pt_pool_kernel<256,%u,%u,%s,%s,%u,%s>", slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
 }
 
+#ifndef MIRT_FAST_MATH
 hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream)
 {
     const uint64_t total = (uint64_t)a.band_rows * a.width;
@@ -1466,5 +1489,7 @@ hipError_t launch_deinterleave(const DeinterleaveArgs& a, hipStream_t stream)
     hipLaunchKernelGGL(deinterleave_kernel, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
+#endif
 
+}  // namespace MIRT_KNS
 }  // namespace mirt
