@@ -80,7 +80,8 @@ def test_scene_errors_match_oracle(gpu_ctx, oracle):
 def test_scene_too_large_and_null_pointers(gpu_ctx):
     cam = simple_camera(8, 8)
     mats, tex = m.flatten_materials([m.Material.Dielectric(1.5)] * 3)
-    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 4000          # 128 KB > the 120 KB LDS budget
+    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 5000          # 160 KB > the 120 KB LDS budget of the flat kernels, and more
+                                                                       # than the 4095 spheres a grid build can index
     assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
     lib = m.lib()
     assert lib.mirt_ctx_set_scene(gpu_ctx._h, None) == _abi.MIRT_ERR_NULL_POINTER
@@ -318,6 +319,6 @@ def test_set_scene_is_failure_atomic(gpu_ctx):
     want = gpu_ctx.render(p)
     cam = simple_camera(8, 8)
     mats, tex = m.flatten_materials([m.Material.Dielectric(1.5)] * 3)
-    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 4000
+    many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 5000
     assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
     assert_images_equal(gpu_ctx.render(p), want, "old scene intact after a rejected set_scene")

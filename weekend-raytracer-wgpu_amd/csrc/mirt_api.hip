@@ -158,17 +158,27 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     h.off_big = (uint32_t)hdr_u16;
     h.off_start = h.off_big + (uint32_t)big.size();
     h.off_items = h.off_start + ncells + 1;
-    size_t total_u16 = (size_t)h.off_items + n_items;
-    total_u16 = (total_u16 + 7) & ~size_t(7);
-    h.total_bytes = (uint32_t)(total_u16 * 2);
+    size_t bytes = ((size_t)h.off_items + n_items) * 2;
+    h.off_ops = (uint32_t)bytes;                                  // u8 per sphere, filled by the caller (needs the materials)
+    bytes = (bytes + n + 15) & ~size_t(15);
+    h.off_big_recs = (uint32_t)bytes;
+    bytes += big.size() * 16;
+    h.off_item_recs = (uint32_t)bytes;
+    bytes += n_items * 16;
+    h.total_bytes = (uint32_t)bytes;
     blob.assign(h.total_bytes, 0);
     uint16_t* u = reinterpret_cast<uint16_t*>(blob.data());
     std::memcpy(blob.data(), &h, sizeof h);
-    for (size_t i = 0; i < big.size(); ++i) u[h.off_big + i] = big[i];
+    // test record of sphere i: centre and r*r, the first half of its PreparedSphere (same IEEE product as set_scene's)
+    auto put_rec = [&](size_t byte_off, uint16_t i) {
+        const float rec[4] = { sph[i].center[0], sph[i].center[1], sph[i].center[2], sph[i].radius * sph[i].radius };
+        std::memcpy(blob.data() + byte_off, rec, 16);
+    };
+    for (size_t i = 0; i < big.size(); ++i) { u[h.off_big + i] = big[i]; put_rec(h.off_big_recs + 16 * i, big[i]); }
     uint32_t pos = 0;
     for (uint32_t c = 0; c < ncells; ++c) {
         u[h.off_start + c] = (uint16_t)pos;
-        for (uint16_t id : lists[c]) u[h.off_items + pos++] = id;
+        for (uint16_t id : lists[c]) { put_rec(h.off_item_recs + 16 * (size_t)pos, id); u[h.off_items + pos++] = id; }
     }
     u[h.off_start + ncells] = (uint16_t)pos;
     return blob;
@@ -247,6 +257,7 @@ struct MirtContext {
     unsigned char* d_grid = nullptr;        // uniform grid blob (many-sphere scenes), see build_grid
     size_t cap_grid = 0;
     uint32_t grid_bytes = 0;
+    bool     grid_packable = false;          // every grid dimension <= 1024: a cell fits the pool kernel's packed cell word
     bool     fits_flat = true;               // spheres + materials fit the LDS budget (flat kernels usable)
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;
@@ -447,9 +458,9 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
     // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
     const bool fits_flat = kx::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
-    const std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell);
+    std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell);
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
-                           kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;
+                           kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;   // camera (+ sky) + the blob
     if (!fits_flat && !fits_grid)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "%u spheres + %u materials exceed the %u-byte LDS budget", s->n_spheres,
                     s->n_materials, mirt::kMaxLdsBytes);
@@ -524,6 +535,10 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
             }
         }
     }
+    if (!grid.empty()) {                         // routine queue of every sphere, for the grid builds (GridHeader.off_ops)
+        const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
+        for (uint32_t i = 0; i < s->n_spheres; ++i) grid[gh->off_ops + i] = (unsigned char)prep[i].op;
+    }
     int rc;
     if ((rc = ensure_capacity(&c->d_pmats, &c->cap_pmats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_spheres, &c->cap_spheres, (size_t)s->n_spheres)) != MIRT_OK) return rc;
@@ -537,6 +552,11 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
     {
         c->grid_bytes = fits_grid ? (uint32_t)grid.size() : 0u;
+        c->grid_packable = false;
+        if (fits_grid) {
+            const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
+            c->grid_packable = gh->dims[0] <= 1024u && gh->dims[1] <= 1024u && gh->dims[2] <= 1024u;
+        }
         if (fits_grid) {
             if ((rc = ensure_capacity(&c->d_grid, &c->cap_grid, grid.size())) != MIRT_OK) return rc;
             HIP_TRY(hipMemcpy(c->d_grid, grid.data(), grid.size(), hipMemcpyHostToDevice));
@@ -632,17 +652,17 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
     const size_t scene_lds_g = kx::scene_lds_bytes_grid(c->n_spheres, hosek);
-    // counting launches keep the reference's flat scan (their counters are then the reference's) unless
-    // MIRT_FLAG_COUNT_GRID asks for the work of the grid build that renders the scene in production
     const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
-    const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pc.lds_bytes;
-    const uint32_t pool_grid_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_grid_block ? lds_pool_grid_block : 1)) * (pc.threads / 64u);
-    bool pool_grid = grid_ok && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
+    const mirt::PoolConfig pcg = kx::pool_config_grid(pool_nq);       // 512-thread blocks, OP_WALK queue, cell word per slot
+    const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pcg.lds_bytes;
+    const uint32_t pool_grid_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_grid_block ? lds_pool_grid_block : 1)) * (pcg.threads / 64u);
+    bool pool_grid = grid_ok && c->grid_packable && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
                      lds_pool_grid_block <= (size_t)c->lds_per_block && !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
                       (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 12));
     if (tune.pool_grid == 0) pool_grid = false;
     if (pool_grid) pool = true;
+    const mirt::PoolConfig pcu = pool_grid ? pcg : pc;                 // the geometry of the pool kernel that will run
     const uint32_t resident_pool_waves = pool_grid ? pool_grid_waves_per_cu : pool_waves_per_cu;
 
     mirt::RenderArgs a{};
@@ -697,7 +717,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block);
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
-    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pc.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pc.lds_bytes : 0));
+    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
@@ -714,12 +734,12 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     uint32_t blocks;
     if (pool) {
         uint32_t per_cu = (uint32_t)(c->lds_per_cu / (a.lds_bytes ? a.lds_bytes : 1));
-        const uint32_t by_waves = 32u / (pc.threads / 64u);   // upper bound; LDS decides (6 blocks of 4 waves with 112-slot pools)
+        const uint32_t by_waves = 32u / (pcu.threads / 64u);   // upper bound; LDS decides (6 blocks of 4 waves with 112-slot pools)
         if (per_cu > by_waves) per_cu = by_waves;
         if (tune.pool_blocks_per_cu >= 1 && tune.pool_blocks_per_cu < per_cu) per_cu = tune.pool_blocks_per_cu;
         if (per_cu == 0u) per_cu = 1u;
         blocks = (uint32_t)c->cu_count * per_cu;
-        const uint32_t units_per_block = pc.threads / 64u;
+        const uint32_t units_per_block = pcu.threads / 64u;
         const uint32_t need = (a.n_units + units_per_block - 1) / units_per_block;
         if (blocks > need) blocks = need;
     } else {
@@ -731,7 +751,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (blocks == 0) blocks = 1;
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
-    const uint32_t launched_waves = blocks * ((pool ? pc.threads : mirt::kBlockThreads) / 64u);
+    const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));

@@ -40,6 +40,13 @@ static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
 // visits only the cells a ray crosses (3D-DDA) plus a short list of "big" spheres.  The grid is
 // CONSERVATIVE (every sphere is listed in all cells its slightly enlarged bounding box touches) and the
 // hit rule breaks ties by sphere index, so the result is identical to the reference's flat scan.
+// Layout of the blob (all of it is staged into LDS; the kernels of a grid build read NO other sphere data from LDS):
+//   GridHeader | big ids [n_big] u16 | cell starts [ncells + 1] u16 | item ids [n_items] u16 (ascending within a cell)
+//   | routine queue of every sphere [n_spheres] u8 (PreparedSphere.op)
+//   | 16-byte aligned: test records {cx, cy, cz, r^2} of the big spheres [n_big] | of the items [n_items], in list order.
+// The records are COPIES of the first half of the spheres' PreparedSphere (a sphere listed in k cells is stored k
+// times): a test then needs ONE LDS round trip (record + id, independent addresses) instead of two dependent ones
+// (id, then the sphere), which is what bounds the walk (4 waves per SIMD, LDS-latency-bound).
 struct GridHeader {
     float    org[3];        // lower corner
     float    cell[3];       // cell size per axis
@@ -50,7 +57,9 @@ struct GridHeader {
     uint32_t off_start;     // [ncells + 1] first item of each cell
     uint32_t off_items;     // sphere ids, ascending within a cell
     uint32_t total_bytes;   // multiple of 16
-    uint32_t _pad[3];
+    uint32_t off_ops;       // BYTE offset of the per-sphere routine-queue table
+    uint32_t off_big_recs;  // BYTE offsets (multiples of 16) of the test records
+    uint32_t off_item_recs;
 };
 static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte copies");
 constexpr uint32_t kGridMinSpheres = 32;
@@ -65,6 +74,7 @@ constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 K
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
 constexpr uint32_t kDefaultPoolConfig = 0;
 constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel
+constexpr uint32_t kGridPoolThreads = 512; // pool kernel, grid build: threads per block
 constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cannot keep the pool full: strip kernel
 
 enum CounterSlot : uint32_t {
@@ -127,6 +137,7 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, 
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
+PoolConfig pool_config_grid(uint32_t nq);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
 // template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID>
 void       pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len);

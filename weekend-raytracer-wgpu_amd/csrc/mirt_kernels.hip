@@ -40,12 +40,14 @@ struct SceneLds {
 
 // Cooperative global -> LDS copy of the scene tables, 16 B per thread per step.
 // PT = false stages the reference-layout material table, PT = true the prepared one.
+// GRID builds (MATS_IN_LDS = false) stage neither the materials nor the spheres: what their sphere tests read lives in
+// the grid blob (stage_grid), and a hit reads its sphere and material from global memory / L2 once.
 template <bool PT, bool MATS_IN_LDS = true>
 MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hosek)
 {
     constexpr uint32_t kMatQuads = PT ? sizeof(PreparedMaterial) / 16 : sizeof(MirtMaterial) / 16;
     const uint32_t n_cam = sizeof(MirtGpuCamera) / 16;
-    const uint32_t n_sph = A.n_spheres * 2;
+    const uint32_t n_sph = MATS_IN_LDS ? A.n_spheres * 2 : 0u;
     const uint32_t n_mat = MATS_IN_LDS ? A.n_mats * kMatQuads : 0u;
     const uint32_t n_sky = hosek ? sizeof(MirtSkyState) / 16 : 0;
     uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -70,7 +72,7 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     __syncthreads();
     SceneLds S;
     S.cam = reinterpret_cast<const float*>(smem);
-    S.spheres = reinterpret_cast<const PreparedSphere*>(smem + 16 * n_cam);
+    S.spheres = MATS_IN_LDS ? reinterpret_cast<const PreparedSphere*>(smem + 16 * n_cam) : A.spheres;
     S.mats = reinterpret_cast<const MirtMaterial*>(smem + 16 * (n_cam + n_sph));
     S.pmats = MATS_IN_LDS ? reinterpret_cast<const PreparedMaterial*>(smem + 16 * (n_cam + n_sph)) : A.pmats;
     S.sky = hosek ? reinterpret_cast<const float*>(smem + 16 * (n_cam + n_sph + n_mat)) : nullptr;
@@ -80,8 +82,8 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
 
 MIRT_DEV size_t scene_lds_bytes_dev(uint32_t n_spheres, uint32_t n_mats, bool hosek, bool mats_in_lds = true)
 {
-    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) +
-           (mats_in_lds ? (size_t)n_mats * sizeof(PreparedMaterial) : 0) + (hosek ? sizeof(MirtSkyState) : 0);
+    return sizeof(MirtGpuCamera) + (mats_in_lds ? (size_t)n_spheres * sizeof(PreparedSphere) + (size_t)n_mats * sizeof(PreparedMaterial) : 0) +
+           (hosek ? sizeof(MirtSkyState) : 0);
 }
 
 // compact output row -> absolute image row (MirtParams contract, include/mirt.h)
@@ -474,17 +476,20 @@ MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
 // sphere is registered in all cells its (slightly enlarged) bounding box overlaps.
 struct GridLds {
     const GridHeader*     h;
-    const unsigned short* big;
+    const unsigned short* big;        // ids of the big spheres
     const unsigned short* start;
-    const unsigned short* items;
+    const unsigned short* items;      // ids of the cells' items
+    const unsigned char*  ops;        // routine queue of every sphere (PreparedSphere.op)
+    const float4*         big_recs;   // {centre, r^2} of the big spheres, in list order
+    const float4*         item_recs;  // ... of the items, in list order
 };
 
+// one sphere test from its record s4 = {centre, r^2} (a copy of the first half of PreparedSphere i)
 template <bool COUNT>
-MIRT_DEV void test_sphere(const SceneLds& S, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best,
+MIRT_DEV void test_sphere(const float4 s4, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best,
                           Work<COUNT>& work)
 {
     if (alive) work.add(kCntTests);                              // grid builds count the tests a lane really performs
-    const float4 s4 = reinterpret_cast<const float4*>(S.spheres)[2 * i];
     const f3 oc = ro - mk(s4.x, s4.y, s4.z);
     const float b = dot(oc, rd);
     const float cq = dot(oc, oc) - s4.w;
@@ -514,7 +519,42 @@ MIRT_DEV GridLds stage_grid(const RenderArgs& A, unsigned char* gdst)
     G.big = base + G.h->off_big;
     G.start = base + G.h->off_start;
     G.items = base + G.h->off_items;
+    G.ops = gdst + G.h->off_ops;
+    G.big_recs = reinterpret_cast<const float4*>(gdst + G.h->off_big_recs);
+    G.item_recs = reinterpret_cast<const float4*>(gdst + G.h->off_item_recs);
     return G;
+}
+
+// the big spheres, four records in flight per LDS round trip (addresses are wave-uniform: broadcast reads)
+template <bool COUNT>
+MIRT_DEV void test_big_spheres(const GridLds& G, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best, Work<COUNT>& work)
+{
+    const uint32_t n_big = G.h->n_big;
+    uint32_t j = 0;
+    for (; j + 4 <= n_big; j += 4) {
+        const float4 r0 = G.big_recs[j], r1 = G.big_recs[j + 1], r2 = G.big_recs[j + 2], r3 = G.big_recs[j + 3];
+        const uint32_t i0 = G.big[j], i1 = G.big[j + 1], i2 = G.big[j + 2], i3 = G.big[j + 3];
+        test_sphere<COUNT>(r0, i0, ro, rd, a, inv_a, alive, closest, best, work);
+        test_sphere<COUNT>(r1, i1, ro, rd, a, inv_a, alive, closest, best, work);
+        test_sphere<COUNT>(r2, i2, ro, rd, a, inv_a, alive, closest, best, work);
+        test_sphere<COUNT>(r3, i3, ro, rd, a, inv_a, alive, closest, best, work);
+    }
+    for (; j < n_big; ++j) test_sphere<COUNT>(G.big_recs[j], G.big[j], ro, rd, a, inv_a, alive, closest, best, work);
+}
+
+// the items [first, first + count) of each lane's cell, two records in flight per LDS round trip
+template <bool COUNT>
+MIRT_DEV void test_cell_items(const GridLds& G, uint32_t first, uint32_t count, f3 ro, f3 rd, float a, float inv_a, float& closest, int& best,
+                              Work<COUNT>& work)
+{
+    for (uint32_t n = 0; __ballot(n < count); n += 2) {
+        const bool on0 = n < count, on1 = n + 1 < count;
+        const uint32_t k0 = on0 ? first + n : 0u, k1 = on1 ? first + n + 1 : 0u;
+        const float4 r0 = G.item_recs[k0], r1 = G.item_recs[k1];
+        const uint32_t i0 = G.items[k0], i1 = G.items[k1];
+        test_sphere<COUNT>(r0, i0, ro, rd, a, inv_a, on0, closest, best, work);
+        if (__ballot(on1)) test_sphere<COUNT>(r1, i1, ro, rd, a, inv_a, on1, closest, best, work);
+    }
 }
 
 template <bool COUNT>
@@ -527,7 +567,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
     int best = -1;
     const GridHeader& H = *G.h;
     if (alive) work.add(kCntRays);
-    for (uint32_t j = 0; j < H.n_big; ++j) test_sphere<COUNT>(S, G.big[j], ro, rd, a, inv_a, alive, closest, best, work);
+    test_big_spheres<COUNT>(G, ro, rd, a, inv_a, alive, closest, best, work);
 
     // clip the ray against the grid's box
     const f3 org = mk(H.org[0], H.org[1], H.org[2]);
@@ -577,11 +617,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
             first = G.start[c];
             count = (uint32_t)G.start[c + 1] - first;
         }
-        for (uint32_t n = 0; __ballot(n < count); ++n) {
-            const bool on = n < count;
-            const uint32_t i = on ? (uint32_t)G.items[first + n] : 0u;
-            test_sphere<COUNT>(S, i, ro, rd, a, inv_a, on, closest, best, work);
-        }
+        test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
         if (walking) {
             const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
             if (closest <= t_exit || t_exit > tmax) {
@@ -597,6 +633,102 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
     }
     closest_out = closest;
     return best;
+}
+
+// The same walk in instalments, for the pool kernel: a FRESH call tests the big spheres, clips the ray against the grid
+// and enters it; every call then visits at most `budget` cells per lane and reports the lanes that are not finished
+// (`walking`), whose state -- closest, best, the packed cell (x | y << 10 | z << 20) -- the pool keeps in the path's
+// slot until a later OP_WALK step RESUMES it.  Lanes finish after very different numbers of cells (3.4 on average on
+// the RTIOW scene, dozens for rays that graze the ground): cutting the walk into instalments lets the pool re-compact
+// the unfinished paths instead of idling the finished lanes (36 % lane use in the un-cut walk of nearest_hit_grid).
+// A resumed instalment recomputes the per-axis crossing parameters from the cell index with the formula the fresh
+// walk starts from; the cells visited may differ from the uncut walk's in the last bit of a crossing parameter,
+// which the conservative binning absorbs exactly as it absorbs the rounding of `tx += ddx` (see GridLds above).
+
+template <bool COUNT>
+MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool active, bool resume /* wave-uniform */, uint32_t budget,
+                        float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane)
+{
+    const float a = dot(rd, rd);
+    const float inv_a = rcp_(a);
+    const GridHeader& H = *G.h;
+    const f3 org = mk(H.org[0], H.org[1], H.org[2]);
+    const f3 cell = mk(H.cell[0], H.cell[1], H.cell[2]);
+    const int dx = (int)H.dims[0], dy = (int)H.dims[1], dz = (int)H.dims[2];
+    const float kHuge = 3.0e38f;
+    // The crossing parameters only STEER the walk (which cells, when to stop); the hit itself is decided by the exact
+    // sphere tests.  An error of a few ulp in them is absorbed by the conservative binning (cells are enlarged by
+    // 1e-3 cell, GridLds above) exactly like the rounding of `tx += ddx`, so the hardware reciprocal (1 ulp, one
+    // instruction, no range guard) is enough here; every build and the resumed instalments use the same one.
+    const f3 inv_d = mk(rd.x != 0.0f ? __builtin_amdgcn_rcpf(rd.x) : kHuge, rd.y != 0.0f ? __builtin_amdgcn_rcpf(rd.y) : kHuge,
+                        rd.z != 0.0f ? __builtin_amdgcn_rcpf(rd.z) : kHuge);
+    const f3 hi = mk(fma_((float)dx, cell.x, org.x), fma_((float)dy, cell.y, org.y), fma_((float)dz, cell.z, org.z));
+    // the ray's parameter range inside the grid's box (both modes: tmax ends the walk)
+    float tmin = 0.0f, tmax = kMaxT;
+    bool inside = active;
+    {
+        const float o[3] = { ro.x, ro.y, ro.z }, d[3] = { rd.x, rd.y, rd.z }, id[3] = { inv_d.x, inv_d.y, inv_d.z };
+        const float lo3[3] = { org.x, org.y, org.z }, hi3[3] = { hi.x, hi.y, hi.z };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (d[k] != 0.0f) {
+                const float ta = (lo3[k] - o[k]) * id[k], tb = (hi3[k] - o[k]) * id[k];
+                tmin = max_(tmin, (ta < tb) ? ta : tb);
+                tmax = (((ta < tb) ? tb : ta) < tmax) ? ((ta < tb) ? tb : ta) : tmax;
+            } else {
+                inside = inside && (o[k] >= lo3[k]) && (o[k] <= hi3[k]);
+            }
+        }
+    }
+    int cx, cy, cz;
+    if (!resume) {
+        closest = kMaxT;
+        best = -1;
+        if (active) work.add(kCntRays);
+        test_big_spheres<COUNT>(G, ro, rd, a, inv_a, active, closest, best, work);
+        walking = inside && (tmin <= tmax) && (tmin < closest);
+        const f3 inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
+        const f3 p0 = fma3(tmin, rd, ro);
+        cx = (int)((p0.x - org.x) * inv_cell.x); cy = (int)((p0.y - org.y) * inv_cell.y); cz = (int)((p0.z - org.z) * inv_cell.z);
+        cx = cx < 0 ? 0 : (cx >= dx ? dx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy);
+        cz = cz < 0 ? 0 : (cz >= dz ? dz - 1 : cz);
+    } else {
+        walking = active;
+        cx = (int)(cellp & 1023u); cy = (int)((cellp >> 10) & 1023u); cz = (int)((cellp >> 20) & 1023u);
+    }
+    const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
+    // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
+    float tx = rd.x != 0.0f ? (fma_((float)(cx + (sx > 0 ? 1 : 0)), cell.x, org.x) - ro.x) * inv_d.x : kHuge;
+    float ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
+    float tz = rd.z != 0.0f ? (fma_((float)(cz + (sz > 0 ? 1 : 0)), cell.z, org.z) - ro.z) * inv_d.z : kHuge;
+    const float ddx = rd.x != 0.0f ? abs_(cell.x * inv_d.x) : kHuge;
+    const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
+    const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
+
+    for (uint32_t it = 0; it < budget && __ballot(walking); ++it) {
+        uint32_t first = 0, count = 0;
+        if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
+        if (walking) {
+            const uint32_t c = (uint32_t)((cz * dy + cy) * dx + cx);
+            first = G.start[c];
+            count = (uint32_t)G.start[c + 1] - first;
+        }
+        test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
+        if (walking) {
+            const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
+            if (closest <= t_exit || t_exit > tmax) {
+                walking = false;                               // nearest hit is final, or the ray left the grid
+            } else if (tx <= ty && tx <= tz) {
+                cx += sx; tx += ddx; walking = (cx >= 0) && (cx < dx);
+            } else if (ty <= tz) {
+                cy += sy; ty += ddy; walking = (cy >= 0) && (cy < dy);
+            } else {
+                cz += sz; tz += ddz; walking = (cz >= 0) && (cz < dz);
+            }
+        }
+    }
+    cellp = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);      // meaningful where `walking` is still set
 }
 
 MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
@@ -820,7 +952,9 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
             if (best >= 0) {
                 work.add(kCntHits);
                 // sphereIntersection wgsl:431-440
-                const PreparedSphere sp = S.spheres[best];
+                PreparedSphere sp;
+                if constexpr (GRID) sp = A.spheres[best];           // grid builds keep no sphere table in LDS: one global read per hit
+                else sp = S.spheres[best];
                 const f3 hp = fma3(closest, rd, ro);
                 const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
                 const PreparedMaterial* m = &S.pmats[sp.material_idx];
@@ -954,6 +1088,14 @@ constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 #define MIRT_FF_MIN 64
 #endif
 constexpr uint32_t kFastForwardMin = MIRT_FF_MIN;
+// pool kernel, grid builds: cells a path may visit in the step that starts its walk / in an OP_WALK step that resumes it
+#ifndef MIRT_WALK_FRESH
+#define MIRT_WALK_FRESH 4
+#endif
+#ifndef MIRT_WALK_RESUME
+#define MIRT_WALK_RESUME 4
+#endif
+constexpr uint32_t kWalkCellsFresh = MIRT_WALK_FRESH, kWalkCellsResume = MIRT_WALK_RESUME;
 
 // ------------------------------------------------------------------------------------------
 // render_pt_pool — wave-private path pool: every wave-instruction runs ONE shading routine
@@ -973,13 +1115,15 @@ constexpr uint32_t kFastForwardMin = MIRT_FF_MIN;
 // accumulators, the item counter and all queue depths in SGPRs.  Nothing is shared between waves after the
 // scene has been staged: no barrier, no inter-wave atomic.  (A block-level pool with barriers was measured
 // 20 % slower)
-template <uint32_t SLOTS, uint32_t NQ>
+template <uint32_t SLOTS, uint32_t NQ, bool GRID = false>
 struct WavePoolLayout {
+    static constexpr uint32_t kQueues   = NQ + 1 + (GRID ? 1 : 0);            // scatter queues, OP_GEN, and OP_WALK in grid builds
     static constexpr uint32_t kRing     = SLOTS;                              // per-queue stack capacity: every slot could sit in one queue
     static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
-    static constexpr uint32_t kOffRing  = kOffAcc + kStripPixels * 3 * 8;     // [NQ + 1][kRing] u8
-    static constexpr uint32_t kBytes    = ((kOffRing + (NQ + 1) * kRing + 15) / 16) * 16;
+    static constexpr uint32_t kOffCell  = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32: grid cell of a path whose walk is cut (GRID)
+    static constexpr uint32_t kOffRing  = kOffCell + (GRID ? SLOTS * 4 : 0);  // [kQueues][kRing] u8
+    static constexpr uint32_t kBytes    = ((kOffRing + kQueues * kRing + 15) / 16) * 16;
 };
 
 // GRID = true (many-sphere scenes): nearest hit through the uniform grid staged behind the spheres; the material
@@ -987,8 +1131,8 @@ struct WavePoolLayout {
 template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, uint32_t NQ = 5, bool GRID = false>
 __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
 {
-    using Lay = WavePoolLayout<SLOTS, NQ>;
-    constexpr uint32_t OP_GEN = NQ, kNumOps = NQ + 1;
+    using Lay = WavePoolLayout<SLOTS, NQ, GRID>;
+    constexpr uint32_t OP_GEN = NQ, OP_WALK = NQ + 1, kNumOps = Lay::kQueues;
     static_assert(NQ >= 1 && NQ < kMaxQueues, "scatter queues");
     constexpr uint32_t RING = Lay::kRing;
     static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 8 == 0, "slot ids are 8 bit");
@@ -1004,6 +1148,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     uint4* const L_state = reinterpret_cast<uint4*>(pool + Lay::kOffState);
     unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
     unsigned char* const L_ring = pool + Lay::kOffRing;
+    uint32_t* const L_cell = reinterpret_cast<uint32_t*>(pool + Lay::kOffCell);
 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -1051,6 +1196,8 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         uint32_t my_k = 0, my_n = 0;                       // wave-uniform: routine of this step, number of paths
         uint32_t slot = 0, pix = 0, bounce = 0, missf = 0;
         int best = 0;
+        float walk_closest = kMaxT;                        // GRID: state of a path whose grid walk is cut (OP_WALK)
+        uint32_t walk_cell = 0;
         f3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), thr = mk(0, 0, 0);
         Rng rng;
         rng.state = 0;
@@ -1082,6 +1229,13 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
                 rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
                 best = has0 ? (int)(fl & 0xfffu) : 0;
+                if constexpr (GRID) {
+                    if (my_k == OP_WALK) {                 // a cut walk: nearest hit so far (none: bit 25) and the cell to resume in
+                        best = (fl >> 25) & 1u ? best : -1;
+                        walk_closest = from_bits(q2.w);
+                        walk_cell = L_cell[slot];
+                    }
+                }
                 thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
                 rng.state = q1.w;
                 pix = (fl >> 12) & 0xfu;
@@ -1118,9 +1272,13 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 generate_primary(A, C, x, y, A.sample_begin + sample, rng, ro, rd);
                 thr = mk(1, 1, 1);
                 bounce = 0;
+            } else if (GRID && my_k == OP_WALK) {
+                // nothing to shade: the tail below resumes these paths' grid walks
             } else {
                 // sphereIntersection wgsl:431-440, then ONE scatter routine for the whole wave
-                const PreparedSphere sp = S.spheres[best];
+                PreparedSphere sp;
+                if constexpr (GRID) sp = A.spheres[best];  // grid builds keep no sphere table in LDS: one global read per hit
+                else sp = S.spheres[best];
                 const f3 hp = ro;                          // computed by the tail of the step that found the hit
                 const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
                 const PreparedMaterial* m = &S.pmats[has ? sp.material_idx : 0u];
@@ -1187,19 +1345,30 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             }
 #endif
             // common tail: bounce limit (wgsl:130), nearest hit, classification
-            const bool trace = alive && bounce < A.num_bounces;
-            if constexpr (COUNT) { if (trace) work.add(kCntLaneIters); }
+            const bool resume = GRID && my_k == OP_WALK;   // wave-uniform
+            const bool trace = alive && (resume || bounce < A.num_bounces);
+            if constexpr (COUNT) { if (trace && !resume) work.add(kCntLaneIters); }
             float closest;
             int nb;
-            if constexpr (GRID) nb = nearest_hit_grid<COUNT>(S, G, ro, rd, trace, closest, work, lane);
-            else nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
-            const bool hit = trace && nb >= 0;
+            bool cut = false;                              // GRID: the walk used up its cell budget: continue in an OP_WALK step
+            if constexpr (GRID) {
+                closest = walk_closest;
+                nb = best;
+                grid_walk<COUNT>(S, G, ro, rd, trace, resume, resume ? kWalkCellsResume : kWalkCellsFresh, closest, nb, walk_cell, cut, work, lane);
+            } else {
+                nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
+            }
+            const bool hit = trace && !cut && nb >= 0;
             if (hit) work.add(kCntHits);
-            const uint32_t miss = (trace && nb < 0) ? 1u : 0u;        // left the scene: OP_GEN adds throughput x sky
-            const f3 hp = fma3(closest, rd, ro);           // rayPointAtParameter (wgsl:442-444); unused after a miss
+            const uint32_t miss = (trace && !cut && nb < 0) ? 1u : 0u;        // left the scene: OP_GEN adds throughput x sky
+            // rayPointAtParameter (wgsl:442-444); unused after a miss; a cut walk keeps the ray's origin instead
+            const f3 hp = cut ? ro : fma3(closest, rd, ro);
             // next routine, branch-free: the queue of a sphere's routine is kept with the sphere.  OP_GEN also when
             // the bounce limit ended the path.
-            const uint32_t new_op = alive ? (hit ? S.spheres[hit ? nb : 0].op : OP_GEN) : OP_NONE;
+            uint32_t hit_op;
+            if constexpr (GRID) hit_op = G.ops[hit ? nb : 0];
+            else hit_op = S.spheres[hit ? nb : 0].op;
+            const uint32_t new_op = alive ? (cut ? OP_WALK : (hit ? hit_op : OP_GEN)) : OP_NONE;
 
             // ---- fast-forward: all paths of this step wait for ONE routine -> run it on them now ----
             if constexpr (kFastForwardMin <= 64u) {
@@ -1208,7 +1377,8 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                     ff = true;
                     my_k = k2;
                     ro = hp;
-                    best = nb < 0 ? 0 : nb;
+                    if constexpr (GRID) { best = (k2 == OP_WALK) ? nb : (nb < 0 ? 0 : nb); walk_closest = closest; }
+                    else best = nb < 0 ? 0 : nb;
                     missf = miss;
                     continue;
                 }
@@ -1216,10 +1386,11 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             }
 
             if (has) {
-                const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24);
+                const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24) | ((nb >= 0 ? 1u : 0u) << 25);
                 L_state[slot * 3 + 0] = make_uint4(bits(hp.x), bits(hp.y), bits(hp.z), packed);
                 L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
-                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), 0u);
+                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), GRID ? bits(closest) : 0u);
+                if constexpr (GRID) { if (cut) L_cell[slot] = walk_cell; }
             }
 #ifdef MIRT_PROBE_UNIFORM_NEXT   // experiment: how often do all lanes of a step move on to ONE routine?
             if constexpr (COUNT) {
@@ -1335,9 +1506,10 @@ size_t scene_lds_bytes(uint32_t n_spheres, uint32_t n_mats, bool pt, bool hosek)
            (size_t)n_mats * (pt ? sizeof(PreparedMaterial) : sizeof(MirtMaterial)) + (hosek ? sizeof(MirtSkyState) : 0);
 }
 
-size_t scene_lds_bytes_grid(uint32_t n_spheres, bool hosek)      // GRID build: materials are not staged
+size_t scene_lds_bytes_grid(uint32_t n_spheres, bool hosek)      // GRID build: camera (+ sky) only; the grid blob holds the rest
 {
-    return sizeof(MirtGpuCamera) + (size_t)n_spheres * sizeof(PreparedSphere) + (hosek ? sizeof(MirtSkyState) : 0);
+    (void)n_spheres;
+    return sizeof(MirtGpuCamera) + (hosek ? sizeof(MirtSkyState) : 0);
 }
 
 
@@ -1406,17 +1578,18 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 // register budget is not the limit
 static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
-    const dim3 g(grid_blocks), b(256);
+    // 512-thread blocks: the scene (spheres + grid, ~27 KB for RTIOW) is staged once per 8 waves, two blocks per CU
+    const dim3 g(grid_blocks), b(kGridPoolThreads);
 #ifdef MIRT_FAST_MATH
     if (count) return hipErrorInvalidValue;
 #else
-    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, true, 5, true>, g, b, a, stream)
-                            : launch_with_lds(render_pt_pool_kernel<256, 112, 1, true, false, 5, true>, g, b, a, stream);
+    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 1, true, true, 5, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 1, true, false, 5, true>, g, b, a, stream);
 #endif
-    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 3, true>, g, b, a, stream)
-                              : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 3, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, true, 5, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<256, 112, 3, false, false, 5, true>, g, b, a, stream);
+    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, true, 3, true>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, false, 3, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, true, 5, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, false, 5, true>, g, b, a, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
@@ -1443,6 +1616,14 @@ PoolConfig pool_config(uint32_t i, uint32_t nq)
     return c;
 }
 
+// the grid build's geometry: 512 threads, 112 slots, one more queue (OP_WALK) and a cell word per slot
+PoolConfig pool_config_grid(uint32_t nq)
+{
+    PoolConfig c{ kGridPoolThreads, 112, 0 };
+    c.lds_bytes = (nq <= 3 ? WavePoolLayout<112, 3, true>::kBytes : WavePoolLayout<112, 5, true>::kBytes) * (kGridPoolThreads / 64);
+    return c;
+}
+
 // builds exist for 3 and for 5 scatter queues; the counting build always has 5
 uint32_t pool_scatter_queues(uint32_t n_routines, bool count) { return (!count && n_routines <= 3) ? 3u : 5u; }
 
@@ -1464,8 +1645,8 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const char* tf[2] = { "false", "true" };
-    uint32_t slots = 112, minw = 6;
-    if (a.grid) { minw = count ? 1 : 3; nq = count ? 5 : (nq <= 3 ? 3 : 5); }
+    uint32_t slots = 112, minw = 6, threads = 256;
+    if (a.grid) { threads = kGridPoolThreads; minw = count ? 1 : 4; nq = count ? 5 : (nq <= 3 ? 3 : 5); }
     else {
         switch (cfg) {
         case 1: slots = 128; minw = 1; break;
@@ -1476,7 +1657,7 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
         }
         if (count) { minw = 1; nq = 5; } else nq = (nq <= 3) ? 3 : 5;
     }
-    snprintf(out, out_len, "render_pt_pool_kernel<256,%u,%u,%s,%s,%u,%s>", slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
+    snprintf(out, out_len, "render_pt_pool_kernel<%u,%u,%u,%s,%s,%u,%s>", threads, slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
 }
 
 #ifndef MIRT_FAST_MATH
