@@ -848,6 +848,9 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.wave_iterations = h[mirt::kCntWaveIters];
         c->stats.grid_cells = h[mirt::kCntCells];
         c->stats.grid_wave_cells = h[mirt::kCntWaveCells];
+#ifdef MIRT_PROBE_TEXELS
+        c->stats.grid_cells = h[12]; c->stats.grid_wave_cells = h[13]; c->stats.lane_iterations = h[14]; c->stats.wave_iterations = h[15];
+#endif
 #ifdef MIRT_PROBE_UNIFORM_NEXT
         c->stats.grid_cells = h[14]; c->stats.grid_wave_cells = h[15]; c->stats.scatter[4] = h[12]; c->stats.roots = h[13];
 #endif

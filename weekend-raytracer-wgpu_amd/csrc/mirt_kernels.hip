@@ -137,7 +137,11 @@ MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height,
     const uint32_t j = sat_u32(uc * (float)width);
     const uint32_t i = sat_u32(vf * (float)height);
     const uint32_t idx = i * width + j;
+#ifdef MIRT_PROBE_NOFETCH    // experiment: the whole lookup EXCEPT the memory access -> the ceiling of any texel cache
+    return mk(from_bits(0x3e800000u | (idx & 1u)), 0.4f, 0.5f);
+#else
     return texel_at(A, (uint64_t)offset + (uint64_t)idx);
+#endif
 }
 
 MIRT_DEV unsigned long long wave_sum_u64(unsigned long long v)
@@ -1304,6 +1308,23 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                     if (has) work.add(kCntScatter4);
                     shade_missing(hn, rng, ndir, att);
                 }
+#ifdef MIRT_PROBE_TEXELS    // experiment (tools/texel_probe.py): would a 64 x 32 texel tile per wave serve the texture fetches?
+                if constexpr (COUNT) {
+                    // lanes whose albedo comes from an image texture (texture 0 of a lambertian / metal material, not 1 x 1)
+                    const bool tex = has && !(m->flags & 1u) && (routine == RT_LAMBERTIAN || routine == RT_METAL);
+                    const unsigned long long tmask = __ballot(tex);
+                    if (tmask) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[0][0]);
+                        const uint32_t tw = bits(t4.x), th = bits(t4.y);
+                        const float u = (0.5f * kFrac1Pi) * (atan2_(-hn.z, hn.x) + kPi), v = kFrac1Pi * acos_(-hn.y);
+                        const uint32_t j = sat_u32(clamp01(u) * (float)tw), i = sat_u32((1.0f - clamp01(v)) * (float)th);
+                        const uint32_t tile = tex ? ((i >> 5) << 16) | (j >> 6) : 0xffffffffu;       // 64 x 32 texel tiles
+                        const uint32_t ref = __builtin_amdgcn_readlane(tile, __builtin_ctzll(tmask));   // the tile the first fetch would load
+                        const bool primary = bounce == 0u;         // first scatter of the path = the camera ray's hit
+                        if (tex) { work.add(primary ? 12 : 14); if (tile == ref) work.add(primary ? 13 : 15); }
+                    }
+                }
+#endif
                 ro = hp;
                 rd = ndir;
                 thr = thr * att;
