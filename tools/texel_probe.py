@@ -47,5 +47,7 @@ res = {
                           "all": round(100.0 * (prim_hit + sec_hit) / max(1, prim + sec), 2)},
 }
 print(json.dumps(res, indent=1))
-(ROOT / "profiles" / f"{tag}_texel_tiles.json").write_text(json.dumps(res, indent=1) + "\n")
+for d in ("profiles", "gpurun_out"):      # gpurun_out/ is what travels back from the GPU box
+    (ROOT / d).mkdir(exist_ok=True)
+    (ROOT / d / f"{tag}_texel_tiles.json").write_text(json.dumps(res, indent=1) + "\n")
 lib.mirt_ctx_destroy(ctx)
