@@ -96,7 +96,7 @@ V3 sub3(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
 
 // Build the uniform grid of mirt_kernels.h over the spheres of a many-sphere scene.  Returns an empty
 // blob when a grid would not help (few spheres, or nothing small enough to bin).
-std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double cell_factor_knob)
+std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double cell_factor_knob, double big_factor_knob)
 {
     std::vector<unsigned char> blob;
     if (n < mirt::kGridMinSpheres || n > 65535u) return blob;
@@ -106,12 +106,13 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
     const float r_med = sorted[n / 2];
     if (!(r_med > 0.0f) || !std::isfinite(r_med)) return blob;
-    // spheres up to 4 median radii go into the grid; the rest (ground planes, hero spheres) are tested for every ray
+    // spheres up to `big_factor` median radii go into the grid; the rest (ground planes) are tested for every ray
+    const float big_factor = (float)(big_factor_knob > 0.0 ? big_factor_knob : 4.0);
     std::vector<uint16_t> big, small;
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (uint32_t i = 0; i < n; ++i) {
         const bool finite = std::isfinite(sph[i].center[0]) && std::isfinite(sph[i].center[1]) && std::isfinite(sph[i].center[2]) && std::isfinite(radii[i]);
-        if (!finite || radii[i] > 4.0f * r_med) { big.push_back((uint16_t)i); continue; }
+        if (!finite || radii[i] > big_factor * r_med) { big.push_back((uint16_t)i); continue; }
         small.push_back((uint16_t)i);
         for (int k = 0; k < 3; ++k) {
             lo[k] = std::min(lo[k], (double)sph[i].center[k] - radii[i]);
@@ -196,6 +197,7 @@ struct Tuning {
     int      by_pixel = -1;           // MIRT_BY_PIXEL=0/1: force lane = sample / lane = pixel in the strip kernel
     uint32_t pool_blocks_per_cu = 0;  // MIRT_POOL_BLOCKS_PER_CU: fewer resident pool blocks (occupancy experiments)
     double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
+    double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
 };
 
 Tuning read_tuning()
@@ -209,6 +211,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_BY_PIXEL")) t.by_pixel = (e[0] == '1') ? 1 : 0;
     if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
     if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
+    if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
 }
 
@@ -458,7 +461,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
     // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
     const bool fits_flat = kx::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
-    std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell);
+    std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell, c->tuning.grid_big);
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
                            kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;   // camera (+ sky) + the blob
     if (!fits_flat && !fits_grid)

@@ -80,6 +80,17 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     return S;
 }
 
+// The kernel's arguments re-read from the kernarg segment through a pointer the compiler cannot see through: values
+// that are needed once per strip (the strip levels, the output and accumulation pointers, the tone-curve flags) are
+// then loaded where they are used instead of sitting in SGPRs across the whole hot loop, which needs all 102 of them.
+MIRT_DEV const RenderArgs& per_strip_args()
+{
+    typedef __attribute__((address_space(4))) const RenderArgs kernarg_args;
+    kernarg_args* p = (kernarg_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const RenderArgs*)p;
+}
+
 MIRT_DEV size_t scene_lds_bytes_dev(uint32_t n_spheres, uint32_t n_mats, bool hosek, bool mats_in_lds = true)
 {
     return sizeof(MirtGpuCamera) + (mats_in_lds ? (size_t)n_spheres * sizeof(PreparedSphere) + (size_t)n_mats * sizeof(PreparedMaterial) : 0) +
@@ -122,8 +133,12 @@ MIRT_DEV uint32_t sat_u8(float f)    // Rust `as u8` (math.rs:15-17)
 
 MIRT_DEV float clamp01(float x) { return (x < 0.0f) ? 0.0f : ((x > 1.0f) ? 1.0f : x); }
 
-MIRT_DEV f3 texel_at(const RenderArgs& A, uint64_t g)
+MIRT_DEV f3 texel_at(const RenderArgs& A_unused, uint64_t g)
 {
+    // the table's address and size are re-read from the kernel arguments here (see per_strip_args): image-texture
+    // lookups are rare in the path-traced kernels' hot loop, and four SGPRs held for them across it are not
+    (void)A_unused;
+    const RenderArgs& A = per_strip_args();
     if (g >= A.n_texels) g = A.n_texels - 1;
     const float* e = A.texels + 3 * g;
     return mk(e[0], e[1], e[2]);
@@ -1161,24 +1176,25 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
 
     for (uint32_t strip = first_unit(); strip < A.n_units; strip = next_unit(A, lane)) {
         // which level does this unit belong to?  (wave-uniform scalar code, once per strip)
+        const RenderArgs& AP = per_strip_args();         // the arguments this prologue needs, loaded here and now
         uint32_t lvl = 0;
 #pragma unroll
-        for (uint32_t l = 1; l < kStripLevels; ++l) lvl = (strip >= A.lvl_unit[l]) ? l : lvl;
-        uint32_t unit0 = A.lvl_unit[0], pix0 = A.lvl_pix[0], pix_end = A.lvl_pix[1];
+        for (uint32_t l = 1; l < kStripLevels; ++l) lvl = (strip >= AP.lvl_unit[l]) ? l : lvl;
+        uint32_t unit0 = AP.lvl_unit[0], pix0 = AP.lvl_pix[0], pix_end = AP.lvl_pix[1];
 #pragma unroll
         for (uint32_t l = 1; l < kStripLevels; ++l)
-            if (lvl == l) { unit0 = A.lvl_unit[l]; pix0 = A.lvl_pix[l]; pix_end = A.lvl_pix[l + 1]; }
+            if (lvl == l) { unit0 = AP.lvl_unit[l]; pix0 = AP.lvl_pix[l]; pix_end = AP.lvl_pix[l + 1]; }
         const uint32_t width_log2 = 4u - lvl;              // 16, 8, 4, 2, 1 pixels
         const uint32_t base_pix = pix0 + ((strip - unit0) << width_log2);
         const uint32_t want_pixels = 1u << width_log2;
         const uint32_t strip_pixels = (pix_end - base_pix < want_pixels) ? (pix_end - base_pix) : want_pixels;
-        const uint32_t total_items = strip_pixels * A.spp;
+        const uint32_t total_items = strip_pixels * AP.spp;
         // scalar (per-strip) pixel addressing: one division here instead of two per work item
-        const uint32_t base_ci = base_pix / A.width;
-        const uint32_t base_x = base_pix - base_ci * A.width;
-        const bool wide = A.width >= kStripPixels;            // a strip then spans at most two rows
-        const uint32_t row0 = abs_row(A, base_ci);
-        const uint32_t row1 = (base_ci + 1 < A.out_rows) ? abs_row(A, base_ci + 1) : row0;
+        const uint32_t base_ci = base_pix / AP.width;
+        const uint32_t base_x = base_pix - base_ci * AP.width;
+        const bool wide = AP.width >= kStripPixels;           // a strip then spans at most two rows
+        const uint32_t row0 = abs_row(AP, base_ci);
+        const uint32_t row1 = (base_ci + 1 < AP.out_rows) ? abs_row(AP, base_ci + 1) : row0;
 
         // all slots start in the OP_GEN queue
         for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_state[s * 3].w = 0u; }
@@ -1432,15 +1448,18 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
         }
 
         // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
-        if (A.accum) {                           // progressive mode: add the exact sums, resolve later
-            if (lane < strip_pixels * 3) A.accum[3ull * base_pix + lane] += L_acc[lane];
-        } else if (lane < strip_pixels) {
-            const uint32_t rgba = pack_rgba(resolve_channel(L_acc[lane * 3 + 0], A.spp, A.flags),
-                                            resolve_channel(L_acc[lane * 3 + 1], A.spp, A.flags),
-                                            resolve_channel(L_acc[lane * 3 + 2], A.spp, A.flags));
-            A.out[base_pix + lane] = rgba;
+        {
+            const RenderArgs& AS = per_strip_args();
+            if (AS.accum) {                      // progressive mode: add the exact sums, resolve later
+                if (lane < strip_pixels * 3) AS.accum[3ull * base_pix + lane] += L_acc[lane];
+            } else if (lane < strip_pixels) {
+                const uint32_t rgba = pack_rgba(resolve_channel(L_acc[lane * 3 + 0], AS.spp, AS.flags),
+                                                resolve_channel(L_acc[lane * 3 + 1], AS.spp, AS.flags),
+                                                resolve_channel(L_acc[lane * 3 + 2], AS.spp, AS.flags));
+                AS.out[base_pix + lane] = rgba;
+            }
+            work.flush(AS.counters, lane);
         }
-        work.flush(A.counters, lane);
     }
 }
 
