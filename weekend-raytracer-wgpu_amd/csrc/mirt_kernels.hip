@@ -456,15 +456,14 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
     int best = -1;
     if (alive) { work.add(kCntRays); work.add(kCntTests, n_spheres); }
     const float4* sph = reinterpret_cast<const float4*>(S.spheres);     // {centre, radius^2} is the first half of a PreparedSphere
-    // The reference's own scenes hold 2-6 spheres: lists of up to four are straight-line code (all reads issued
-    // together, no loop bookkeeping) behind one wave-uniform switch; measured -1.5 % on config 3 (tools/ab_libs.py).
-    if (n_spheres >= 1u && n_spheres <= 4u) {
-        const float4 s0 = sph[0];
-        const float4 s1 = sph[n_spheres > 1u ? 2 : 0], s2 = sph[n_spheres > 2u ? 4 : 0], s3 = sph[n_spheres > 3u ? 6 : 0];
+    // Three spheres -- the headline scene (src/main.rs:539-541) -- are straight-line code: all reads issued together, no
+    // loop bookkeeping.  Measured on config 3 (tools/ab_libs.py, interleaved rounds): -1.5 %; the same treatment for
+    // lists of 1, 2 and 4 spheres behind one switch cost the three-sphere case 1.7 % and was dropped.
+    if (n_spheres == 3u) {
+        const float4 s0 = sph[0], s1 = sph[2], s2 = sph[4];
         hit_sphere<COUNT>(s0, 0, ro, rd, a, inv_a, alive, closest, best, work);
-        if (n_spheres > 1u) hit_sphere<COUNT>(s1, 1, ro, rd, a, inv_a, alive, closest, best, work);
-        if (n_spheres > 2u) hit_sphere<COUNT>(s2, 2, ro, rd, a, inv_a, alive, closest, best, work);
-        if (n_spheres > 3u) hit_sphere<COUNT>(s3, 3, ro, rd, a, inv_a, alive, closest, best, work);
+        hit_sphere<COUNT>(s1, 1, ro, rd, a, inv_a, alive, closest, best, work);
+        hit_sphere<COUNT>(s2, 2, ro, rd, a, inv_a, alive, closest, best, work);
         closest_out = closest;
         return best;
     }
