@@ -656,13 +656,17 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
     const size_t scene_lds_g = kx::scene_lds_bytes_grid(c->n_spheres, hosek);
     const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
-    const mirt::PoolConfig pcg = kx::pool_config_grid(pool_nq);       // 512-thread blocks, OP_WALK queue, cell word per slot
-    const size_t lds_pool_grid_block = scene_lds_g + c->grid_bytes + pcg.lds_bytes;
-    const uint32_t pool_grid_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_grid_block ? lds_pool_grid_block : 1)) * (pcg.threads / 64u);
-    bool pool_grid = grid_ok && c->grid_packable && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
-                     lds_pool_grid_block <= (size_t)c->lds_per_block && !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
+    // one 1024-thread block per CU; its path pools take what scene + grid leave of the block's LDS (counting launches:
+    // the largest geometry only)
+    const size_t lds_beside = scene_lds_g + c->grid_bytes;
+    mirt::PoolConfig pcg = kx::pool_config_grid((size_t)c->lds_per_block > lds_beside ? (size_t)c->lds_per_block - lds_beside : 0);
+    if (count && pcg.slots != mirt::kGridPoolSlotChoices[0]) pcg.slots = 0;
+    const size_t lds_pool_grid_block = lds_beside + pcg.lds_bytes;
+    const uint32_t pool_grid_waves_per_cu = pcg.slots ? (uint32_t)(c->lds_per_cu / lds_pool_grid_block) * (pcg.threads / 64u) : 0u;
+    bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
+                     !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
-                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 12));
+                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 16));
     if (tune.pool_grid == 0) pool_grid = false;
     if (pool_grid) pool = true;
     const mirt::PoolConfig pcu = pool_grid ? pcg : pc;                 // the geometry of the pool kernel that will run
@@ -720,6 +724,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block);
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
+    a.grid_pool_slots = pool_grid ? pcg.slots : 0u;
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "

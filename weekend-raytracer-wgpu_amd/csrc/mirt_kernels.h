@@ -74,7 +74,12 @@ constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 K
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
 constexpr uint32_t kDefaultPoolConfig = 0;
 constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel
-constexpr uint32_t kGridPoolThreads = 512; // pool kernel, grid build: threads per block
+// pool kernel, grid build (many-sphere scenes): ONE 1024-thread block per CU, so that the grid blob (~20 KB for RTIOW)
+// is staged once for all 16 waves and the rest of the 160 KB goes to the path pools.  Measured on RTIOW 1080p x 128 spp:
+// 512 threads x 112 slots, two blocks 17.3 ms; x 128 slots 16.6; 1024 x 144 15.9; 1024 x 152 15.7; one 512-thread
+// block per CU (8 waves) with 160-256 slots 26.3 -- the pools want to be as large as 16 resident waves allow.
+constexpr uint32_t kGridPoolThreads = 1024;
+constexpr uint32_t kGridPoolSlotChoices[3] = { 152, 128, 96 };   // the largest geometry whose block fits LDS is taken
 constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cannot keep the pool full: strip kernel
 
 enum CounterSlot : uint32_t {
@@ -99,6 +104,7 @@ struct RenderArgs {
     unsigned long long*     counters;      // [kNumCounters] of THIS launch (one block per event slot), COUNT builds only
     const unsigned char*    grid;          // nullable: GridHeader + lists (strip kernel, GRID build)
     uint32_t                grid_bytes;
+    uint32_t                grid_pool_slots;   // pool kernel, grid build: slots per wave of the geometry chosen on the host
     uint32_t*               work_counter;  // dynamic work dispenser: THIS launch's own word (one per event slot), preset before the launch
     unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;
@@ -137,7 +143,7 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, 
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
-PoolConfig pool_config_grid(uint32_t nq);
+PoolConfig pool_config_grid(size_t lds_for_pools);   // grid build: slots by the LDS left beside scene + grid (slots = 0: none fits)
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
 // template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID>
 void       pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len);

@@ -1108,10 +1108,10 @@ constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 constexpr uint32_t kFastForwardMin = MIRT_FF_MIN;
 // pool kernel, grid builds: cells a path may visit in the step that starts its walk / in an OP_WALK step that resumes it
 #ifndef MIRT_WALK_FRESH
-#define MIRT_WALK_FRESH 4
+#define MIRT_WALK_FRESH 3
 #endif
 #ifndef MIRT_WALK_RESUME
-#define MIRT_WALK_RESUME 4
+#define MIRT_WALK_RESUME 3
 #endif
 constexpr uint32_t kWalkCellsFresh = MIRT_WALK_FRESH, kWalkCellsResume = MIRT_WALK_RESUME;
 
@@ -1307,6 +1307,18 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 uint32_t routine = A.queue_routine[0];     // wave-uniform dispatch
 #pragma unroll
                 for (uint32_t k = 1; k < NQ; ++k) routine = (my_k == k) ? A.queue_routine[k] : routine;
+                // Grid builds (many-sphere scenes) keep ONE scatter queue and switch on the material per lane: there the
+                // trace -- grid set-up, big spheres, cell walk -- is 70 % of a step and shading the smaller part, so fuller
+                // steps (3 queues share the slots instead of 5) are worth more than undivided routines: -7 % on RTIOW.
+                if constexpr (GRID) {
+                    switch (m->id) {
+                    case 0u: if (has) work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
+                    case 1u: if (has) work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
+                    case 2u: if (has) work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
+                    case 3u: if (has) work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
+                    default: if (has) work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
+                    }
+                } else
                 if (routine == RT_LAMBERTIAN) {
                     if (has) work.add(kCntScatter0);
                     shade_lambertian(A, m, hn, rng, ndir, att);
@@ -1402,7 +1414,7 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
             // next routine, branch-free: the queue of a sphere's routine is kept with the sphere.  OP_GEN also when
             // the bounce limit ended the path.
             uint32_t hit_op;
-            if constexpr (GRID) hit_op = G.ops[hit ? nb : 0];
+            if constexpr (GRID) hit_op = 0u;              // the one scatter queue of a grid build
             else hit_op = S.spheres[hit ? nb : 0].op;
             const uint32_t new_op = alive ? (cut ? OP_WALK : (hit ? hit_op : OP_GEN)) : OP_NONE;
 
@@ -1617,18 +1629,26 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 // register budget is not the limit
 static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
-    // 512-thread blocks: the scene (spheres + grid, ~27 KB for RTIOW) is staged once per 8 waves, two blocks per CU
     const dim3 g(grid_blocks), b(kGridPoolThreads);
+    (void)nq;                                   // grid builds have ONE scatter queue (per-lane material switch)
+    const uint32_t slots = a.grid_pool_slots;
 #ifdef MIRT_FAST_MATH
     if (count) return hipErrorInvalidValue;
 #else
-    if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 1, true, true, 5, true>, g, b, a, stream)
-                            : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 1, true, false, 5, true>, g, b, a, stream);
+    if (count) {                                // the counting build exists for the largest geometry only
+        if (slots != kGridPoolSlotChoices[0]) return hipErrorInvalidValue;
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, false, 1, true>, g, b, a, stream);
+    }
 #endif
-    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, true, 3, true>, g, b, a, stream)
-                              : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, false, 3, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, true, 5, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, 112, 4, false, false, 5, true>, g, b, a, stream);
+    if (slots == kGridPoolSlotChoices[0])
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 4, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 4, false, false, 1, true>, g, b, a, stream);
+    if (slots == kGridPoolSlotChoices[1])
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, false, 1, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, true, 1, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, false, 1, true>, g, b, a, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
@@ -1656,11 +1676,14 @@ PoolConfig pool_config(uint32_t i, uint32_t nq)
 }
 
 // the grid build's geometry: 512 threads, 112 slots, one more queue (OP_WALK) and a cell word per slot
-PoolConfig pool_config_grid(uint32_t nq)
+PoolConfig pool_config_grid(size_t lds_for_pools)
 {
-    PoolConfig c{ kGridPoolThreads, 112, 0 };
-    c.lds_bytes = (nq <= 3 ? WavePoolLayout<112, 3, true>::kBytes : WavePoolLayout<112, 5, true>::kBytes) * (kGridPoolThreads / 64);
-    return c;
+    const uint32_t waves = kGridPoolThreads / 64;
+    const uint32_t bytes[3] = { WavePoolLayout<kGridPoolSlotChoices[0], 1, true>::kBytes * waves, WavePoolLayout<kGridPoolSlotChoices[1], 1, true>::kBytes * waves,
+                                WavePoolLayout<kGridPoolSlotChoices[2], 1, true>::kBytes * waves };
+    for (int i = 0; i < 3; ++i)
+        if (bytes[i] <= lds_for_pools) return PoolConfig{ kGridPoolThreads, kGridPoolSlotChoices[i], bytes[i] };
+    return PoolConfig{ kGridPoolThreads, 0, 0 };
 }
 
 // builds exist for 3 and for 5 scatter queues; the counting build always has 5
@@ -1685,7 +1708,7 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const char* tf[2] = { "false", "true" };
     uint32_t slots = 112, minw = 6, threads = 256;
-    if (a.grid) { threads = kGridPoolThreads; minw = count ? 1 : 4; nq = count ? 5 : (nq <= 3 ? 3 : 5); }
+    if (a.grid) { threads = kGridPoolThreads; slots = a.grid_pool_slots; minw = count ? 1 : 4; nq = 1; }
     else {
         switch (cfg) {
         case 1: slots = 128; minw = 1; break;
