@@ -31,11 +31,14 @@ def rocprof_spelling(kernel_id: str) -> str:
     """'render_pt_pool_kernel<256,112,6,false,false,3,false>' -> the substring rocprofv3 prints
     ('render_pt_pool_kernel<256u, 112u, 6u, false, false, 3u, false>')."""
     name, targs = kernel_id[:kernel_id.index("<")], kernel_id[kernel_id.index("<") + 1:-1].split(",")
+    if "::" not in name:
+        name = "exact_build::" + name            # the default build's namespace (the opt-in one reports "fast_build::...")
     return name + "<" + ", ".join(a + "u" if a.isdigit() else a for a in targs) + ">"
 
 
 def mangled_fragment(kernel_id: str) -> str:
     name, targs = kernel_id[:kernel_id.index("<")], kernel_id[kernel_id.index("<") + 1:-1].split(",")
+    name = name.split("::")[-1]
     enc = "".join(f"Lj{a}E" if a.isdigit() else f"Lb{1 if a == 'true' else 0}E" for a in targs)
     return f"{name}I{enc}E"
 
