@@ -97,15 +97,18 @@ def algorithmic_flops(st: dict, hosek: bool = False, mode: str = "pt", grid: boo
     return float(f)
 
 
-def profiled_traffic(kernel: str):
+def profiled_traffic(kernel: str, workload: str = None):
     """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc_summary.json, written by tools/summarize_profile.py: separate --pmc passes,
-    FETCH_SIZE x2 gfx950 correction).  None if no summary for this kernel exists."""
+    FETCH_SIZE x2 gfx950 correction) of this kernel ON this workload (several configs share a kernel).
+    None if no such summary exists."""
     best = None
     for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json")):
         try:
             d = json.loads(f.read_text())
         except (OSError, ValueError):
+            continue
+        if workload is not None and d.get("workload") != workload:
             continue
         if d.get("kernel_id") == kernel and "hbm_bytes_per_launch" in d.get("derived", {}):
             best = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"].get("valu_issue_busy_pct"),
@@ -469,7 +472,7 @@ def main(argv=None) -> int:
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
         flops = algorithmic_flops(work, mode=cfg["mode"], grid=uses_grid)
-        traffic = profiled_traffic(kernel_name) if world == 1 else None
+        traffic = profiled_traffic(kernel_name, cfg["workload"]) if world == 1 else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
         out_bytes = frame.rows * w * 4
         in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96 + 12 * int(sd.texels.shape[0])
