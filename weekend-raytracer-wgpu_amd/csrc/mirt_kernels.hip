@@ -1474,6 +1474,43 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     }
 }
 
+#ifdef MIRT_ISA_PROBES
+// ------------------------------------------------------------------------------------------
+// ISA probes (tools/isa_mix.py, never part of libmirt.so): one kernel per routine of the path-traced mode, each
+// around the SAME load / store frame (probe_frame = that frame alone), so that the instruction mix of a routine can be
+// read off the compiler's assembly in isolation.  Inputs come from memory and every result is stored: nothing folds.
+// ------------------------------------------------------------------------------------------
+struct ProbeIo { float4 a, b, c; uint4 u; };
+
+#define MIRT_PROBE_KERNEL(NAME, BODY)                                                                              \
+    __global__ __launch_bounds__(256) void NAME(RenderArgs A, const ProbeIo* in, ProbeIo* out)                       \
+    {                                                                                                              \
+        extern __shared__ __align__(16) unsigned char smem[];                                                      \
+        const SceneLds S = stage_scene<true, true>(A, smem, false);                                                \
+        ProbeIo io = in[blockIdx.x * 256 + threadIdx.x];                                                           \
+        f3 ro = mk(io.a.x, io.a.y, io.a.z), rd = mk(io.b.x, io.b.y, io.b.z), hn = mk(io.c.x, io.c.y, io.c.z);    \
+        f3 o0 = ro, o1 = rd;                                                                                       \
+        Rng rng; rng.state = io.u.x;                                                                               \
+        Work<false> work; (void)work; (void)S; (void)hn;                                                           \
+        BODY                                                                                                       \
+        io.a = make_float4(o0.x, o0.y, o0.z, io.a.w); io.b = make_float4(o1.x, o1.y, o1.z, io.b.w); io.u.x = rng.state;          \
+        out[blockIdx.x * 256 + threadIdx.x] = io;                                                                  \
+    }
+
+MIRT_PROBE_KERNEL(probe_frame, { })
+MIRT_PROBE_KERNEL(probe_rng_4_variates, { o0.x = rng.next(); o0.y = rng.next(); o0.z = rng.next(); o1.x = rng.next(); })
+MIRT_PROBE_KERNEL(probe_generate_primary, { const CamRegs C = load_camera(S, A); generate_primary(A, C, io.u.y, io.u.z, io.u.w, rng, o0, o1); })
+MIRT_PROBE_KERNEL(probe_nearest_hit_3_spheres, { float closest; const int nb = nearest_hit<false>(S, 3u, ro, rd, io.u.y != 0u, closest, work);
+                                                  o0 = fma3(closest, rd, ro); io.u.z = (uint32_t)nb; })
+MIRT_PROBE_KERNEL(probe_shade_lambertian, { shade_lambertian(A, &S.pmats[io.u.y], hn, rng, o0, o1); })
+MIRT_PROBE_KERNEL(probe_shade_checkerboard, { shade_checkerboard(A, &S.pmats[io.u.y], ro, hn, rng, o0, o1); })
+MIRT_PROBE_KERNEL(probe_shade_metal, { shade_metal(A, &S.pmats[io.u.y], rd, hn, rng, o0, o1); })
+MIRT_PROBE_KERNEL(probe_shade_dielectric, { shade_dielectric(&S.pmats[io.u.y], rd, hn, rng, o0, o1); })
+MIRT_PROBE_KERNEL(probe_sky_and_accumulate, { const f3 c = sky_color<false>(S, rd);
+                                              io.u.y = to_fixed(ro.x * c.x); io.u.z = to_fixed(ro.y * c.y); io.u.w = to_fixed(ro.z * c.z); })
+MIRT_PROBE_KERNEL(probe_hit_normal, { const PreparedSphere sp = S.spheres[io.u.y]; o0 = sp.inv_r * (ro - mk(sp.cx, sp.cy, sp.cz)); io.u.z = sp.material_idx; })
+#endif  // MIRT_ISA_PROBES
+
 #ifndef MIRT_FAST_MATH       // self-test, resolve and de-interleave live in the exact build only
 // ------------------------------------------------------------------------------------------
 // self-test: the fast sqrt_/rcp_ against the IEEE expansions over ALL 2^32 binary32 patterns
