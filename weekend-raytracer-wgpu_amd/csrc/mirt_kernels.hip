@@ -436,11 +436,16 @@ MIRT_DEV void hit_sphere(const float4 s4, uint32_t i, f3 ro, f3 rd, float a, flo
         const float sq = sqrt_(disc);
         const float t0 = (-b - sq) * inv_a;
         const float t1 = (-b + sq) * inv_a;
-        const bool ok0 = (t0 < closest) && (t0 > kMinT);    // first root, else second (wgsl:415-425), branch-free
-        const bool ok1 = (t1 < closest) && (t1 > kMinT);
-        work.add(kCntRoots, ok0 ? 1u : 2u);
-        const float t = ok0 ? t0 : t1;
-        const bool ok = ok0 || ok1;
+        // first root, else second (wgsl:415-425): `t0 < closest && t0 > MIN_T ? t0 : (t1 < closest && t1 > MIN_T ? t1 : none)`.
+        // t0 <= t1 always (sq >= 0, inv_a > 0), so that is the smaller of the roots above MIN_T, accepted if below
+        // `closest`: two compare+select pairs, one min and one compare, and NO scalar mask arithmetic (the and/and/or of
+        // four compare masks costs three SALU instructions per test, each dearer than a VALU one here).
+        if constexpr (COUNT) work.add(kCntRoots, ((t0 < closest) && (t0 > kMinT)) ? 1u : 2u);
+        const float kInf = __builtin_inff();
+        const float c0 = (t0 > kMinT) ? t0 : kInf;
+        const float c1 = (t1 > kMinT) ? t1 : kInf;
+        const float t = __builtin_fminf(c0, c1);
+        const bool ok = t < closest;
         closest = ok ? t : closest;
         best = ok ? (int)i : best;
     }
