@@ -171,6 +171,14 @@ typedef struct MirtParams {
     uint32_t n_parts;
     uint32_t part;
     uint32_t sample_begin; /* PT: first sample index (progressive accumulation); normally 0 */
+    /* PT: 0 (default) = every sample has its own RNG stream, that of frame_number = sample + 1 at one sample per
+     * frame -- the image then does not depend on how samples are grouped into launches.  n > 0 = the REFERENCE's
+     * stream for `num_samples_per_pixel` = n: frame f = sample / n + 1 seeds the pixel's RNG once (initRng,
+     * wgsl:498-502) and its n samples draw from that one stream in turn (samplePixel, wgsl:105-122), exactly as
+     * Raytracer::render_frame advances (mod.rs:303-351, 626-670).  Needs spp % n == 0 and sample_begin % n == 0;
+     * runs on the lane-per-pixel schedule (a pixel's samples are then sequentially dependent). */
+    uint32_t frame_spp;
+    uint32_t _reserved;    /* 0 */
 } MirtParams;
 
 /* Work counters of the last render on a context (rocprof-independent).  The ray/test/scatter
@@ -213,6 +221,7 @@ typedef enum MirtStatus {
     MIRT_ERR_OUT_BUFFER           = -16, /* out_len too small */
     MIRT_ERR_NO_SCENE             = -17,
     MIRT_ERR_SCENE_TOO_LARGE      = -18, /* spheres+materials do not fit the LDS budget */
+    MIRT_ERR_FRAME_SPP            = -19, /* frame_spp does not divide spp / sample_begin */
     MIRT_ERR_NO_DEVICE            = -20,
     MIRT_ERR_HIP                  = -21,
     MIRT_ERR_ALLOC                = -22

@@ -74,6 +74,8 @@ int mirt_oracle_check(const MirtScene* scene, const MirtParams* params)
     if (params->mode != MIRT_MODE_PARITY && params->mode != MIRT_MODE_PT) return MIRT_ERR_BAD_MODE;
     uint32_t rb, re;
     if (!rows_valid(params, &rb, &re)) return MIRT_ERR_BAD_ROWS;
+    if (params->mode == MIRT_MODE_PT && params->frame_spp != 0 &&
+        (params->spp % params->frame_spp != 0 || params->sample_begin % params->frame_spp != 0)) return MIRT_ERR_FRAME_SPP;
     if (params->mode == MIRT_MODE_PARITY) {
         if (scene->n_spheres > 0) {
             /* layer.rs:345-349 reads material_data[2] on every primary hit */

@@ -326,9 +326,11 @@ static inline uint32_t to_fixed(float c)
 }
 
 /* samplePixel + rayColor for ONE sample (wgsl:105-172) -> fixed-point rgb */
-static void trace_sample(const tctx_t* T, uint32_t x, uint32_t y, uint32_t sample, uint32_t q[3])
+/* `rng` = NULL: the sample's own stream (S1).  Otherwise the caller's running stream of the current frame
+ * (MirtParams.frame_spp > 0: the reference's samplePixel loop, wgsl:105-122, draws all samples of a frame from one). */
+static void trace_sample(const tctx_t* T, uint32_t x, uint32_t y, uint32_t sample, uint32_t q[3], uint32_t* rng)
 {
-    uint32_t st = rng_init(x + y * T->W, sample, T->mix);
+    uint32_t st = rng ? *rng : rng_init(x + y * T->W, sample, T->mix);
     float u = ((float)x + rng_next(&st)) * T->inv_w;
     float v = ((float)y + rng_next(&st)) * T->inv_h;
     tray_t ray = camera_make_ray(T, &st, u, 1.0f - v);
@@ -352,6 +354,7 @@ static void trace_sample(const tctx_t* T, uint32_t x, uint32_t y, uint32_t sampl
     q[0] = to_fixed(thr.x * color.x);
     q[1] = to_fixed(thr.y * color.y);
     q[2] = to_fixed(thr.z * color.z);
+    if (rng) *rng = st;              /* the frame's stream continues with the next sample */
 }
 
 /* ---------------- resolve (S5) ---------------- */
@@ -422,9 +425,17 @@ int mirt_oracle_render_pt(const MirtScene* scene, const MirtParams* params, uint
             uint32_t y = mirt_params_out_row_index_impl(params, i);
             for (uint32_t x = 0; x < W; ++x) {
                 uint64_t sum[3] = { 0, 0, 0 };
+                uint32_t frame_rng = 0;
                 for (uint32_t s = 0; s < params->spp; ++s) {
                     uint32_t q[3];
-                    trace_sample(&T, x, y, params->sample_begin + s, q);
+                    const uint32_t sample = params->sample_begin + s;
+                    if (params->frame_spp) {
+                        /* frame f = sample / n + 1 seeds once: rng_init's `sample + 1` is the frame number */
+                        if (sample % params->frame_spp == 0) frame_rng = rng_init(x + y * T.W, sample / params->frame_spp, T.mix);
+                        trace_sample(&T, x, y, sample, q, &frame_rng);
+                    } else {
+                        trace_sample(&T, x, y, sample, q, NULL);
+                    }
                     sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2];
                 }
                 size_t pi = (size_t)i * W + x;

@@ -120,6 +120,8 @@ pub struct MirtParams {
     pub n_parts: u32,
     pub part: u32,
     pub sample_begin: u32,
+    pub frame_spp: u32,
+    pub _reserved: u32,
 }
 
 #[repr(C)]

@@ -408,3 +408,54 @@ def test_grid_counting_build(gpu_ctx, oracle, kernel):
     assert st_flat["grid_cells"] == 0 and st_flat["sphere_tests"] == st_flat["rays"] * len(sd.spheres)
     assert 0 < st_grid["sphere_tests"] < st_flat["sphere_tests"] // 10
     assert st_grid["grid_cells"] > 0 and st_grid["grid_cells"] <= 64 * st_grid["grid_wave_cells"]
+
+
+@pytest.mark.parametrize("scene,w,h,spp,n", [("three_spheres", 96, 64, 8, 2), ("three_spheres", 61, 47, 12, 4), ("earth", 64, 40, 6, 1),
+                                              ("main_rs_scene", 80, 48, 128, 2), ("rtiow_final", 64, 36, 4, 2), ("three_spheres", 3, 1, 70, 1)])
+def test_reference_frame_stream_vs_oracle(gpu_ctx, oracle, scene, w, h, spp, n):
+    """MirtParams.frame_spp = n: frame f seeds the pixel's RNG once and its n samples draw from that stream in turn
+    (initRng / samplePixel, wgsl:498-502, 105-122) -- image, exact sums and work counters against the oracle; forced kernel
+    flags must not matter (the lane-per-pixel schedule is the only one that can run it)."""
+    sd = scene_data(scene, w, h)
+    gpu_ctx.set_scene(sd)
+    for flags in (0, m.MIRT_FLAG_KERNEL_POOL, LINEAR | m.MIRT_FLAG_COUNT_WORK):
+        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags, frame_spp=n)
+        got = gpu_ctx.render(p)
+        assert gpu_ctx.last_kernel().endswith(",true>") and "strip" in gpu_ctx.last_kernel()
+        gs = gpu_ctx.stats()
+        want = oracle.render(sd, p)
+        assert_images_equal(got, want, f"{scene} frame_spp {n} flags {flags}")
+        if flags & m.MIRT_FLAG_COUNT_WORK:
+            os_ = oracle.stats()
+            assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+    # frame by frame through the accumulation API == all frames in one launch == the oracle's sums
+    p1 = m.make_params(w, h, n, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=n)
+    gpu_ctx.accum_reset(p1)
+    for _ in range(spp // n):
+        gpu_ctx.accum_add(p1)
+    whole = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=n)
+    assert np.array_equal(gpu_ctx.accum_read(p1), oracle.render_pt_sums(sd, whole))
+    if n > 1:
+        assert not np.array_equal(gpu_ctx.render(whole), gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)))
+
+
+def test_frame_stream_param_errors(gpu_ctx, oracle):
+    sd = scene_data("three_spheres", 16, 16)
+    gpu_ctx.set_scene(sd)
+    for kw in (dict(spp=10, frame_spp=4), dict(spp=8, frame_spp=4, sample_begin=2)):
+        p = m.make_params(16, 16, kw.pop("spp"), mode=m.MIRT_MODE_PT, **kw)
+        with pytest.raises(m.MirtError) as e:
+            gpu_ctx.render(p)
+        assert e.value.status_name == "MIRT_ERR_FRAME_SPP"
+        assert oracle.render_status(sd.as_c(), p) == m._abi.MIRT_ERR_FRAME_SPP
+
+
+def test_raytracer_render_frame_with_the_reference_stream(oracle):
+    scene, cam = m.scenes.three_spheres()
+    rp = m.RenderParams(camera=cam, viewport_size=(64, 40), sampling=m.SamplingParams(8, 2, 8))
+    rt = m.Raytracer(scene, rp, reference_stream=True)
+    sd = rt.scene_data()
+    for k in (2, 4, 6, 8, 8):
+        img = rt.render_frame()
+        assert_images_equal(img, oracle.render(sd, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2)), f"after {k} spp")
+    rt.close()

@@ -38,6 +38,7 @@ STATUS = {
     -16: "MIRT_ERR_OUT_BUFFER",
     -17: "MIRT_ERR_NO_SCENE",
     -18: "MIRT_ERR_SCENE_TOO_LARGE",
+    -19: "MIRT_ERR_FRAME_SPP",
     -20: "MIRT_ERR_NO_DEVICE",
     -21: "MIRT_ERR_HIP",
     -22: "MIRT_ERR_ALLOC",
@@ -97,7 +98,7 @@ class MirtParams(C.Structure):
                 ("num_bounces", C.c_uint32), ("mode", C.c_uint32), ("flags", C.c_uint32),
                 ("seed", C.c_uint64), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("tile_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
-                ("sample_begin", C.c_uint32)]
+                ("sample_begin", C.c_uint32), ("frame_spp", C.c_uint32), ("_reserved", C.c_uint32)]
 
 
 class MirtStats(C.Structure):

@@ -313,6 +313,7 @@ const char* mirt_status_string(int status)
     case MIRT_ERR_OUT_BUFFER: return "MIRT_ERR_OUT_BUFFER";
     case MIRT_ERR_NO_SCENE: return "MIRT_ERR_NO_SCENE";
     case MIRT_ERR_SCENE_TOO_LARGE: return "MIRT_ERR_SCENE_TOO_LARGE";
+    case MIRT_ERR_FRAME_SPP: return "MIRT_ERR_FRAME_SPP";
     case MIRT_ERR_NO_DEVICE: return "MIRT_ERR_NO_DEVICE";
     case MIRT_ERR_HIP: return "MIRT_ERR_HIP";
     case MIRT_ERR_ALLOC: return "MIRT_ERR_ALLOC";
@@ -595,6 +596,8 @@ static int check_params(const MirtContext* c, const MirtParams* p)
     if (p->mode != MIRT_MODE_PARITY && p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "unknown mode %u", p->mode);
     uint32_t rb, re;
     if (!rows_valid(p, &rb, &re)) return fail(MIRT_ERR_BAD_ROWS, "invalid row selection [%u,%u) of %u, part %u/%u", p->row_begin, p->row_end, p->height, p->part, p->n_parts);
+    if (p->mode == MIRT_MODE_PT && p->frame_spp != 0 && (p->spp % p->frame_spp != 0 || p->sample_begin % p->frame_spp != 0))
+        return fail(MIRT_ERR_FRAME_SPP, "frame_spp %u must divide spp %u and sample_begin %u", p->frame_spp, p->spp, p->sample_begin);
     if (p->mode == MIRT_MODE_PARITY) {
         if (c->parity_scene_status != MIRT_OK)
             return fail(c->parity_scene_status, "parity mode needs material_data[2] with a valid texture (layer.rs:345-351)");
@@ -651,11 +654,15 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_waves_per_cu >= 16;
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
+    // the reference's per-frame RNG stream makes a pixel's samples sequentially dependent: lane-per-pixel strip kernel only
+    const bool frame_stream = pt && p->frame_spp != 0;
+    if (frame_stream) pool = false;
     if (p->num_bounces > 255u || scene_lds + pc.lds_bytes > (size_t)c->lds_per_block || !c->fits_flat) pool = false;
     // Many-sphere scenes: the pool kernel's grid build keeps spheres + grid + pools in LDS (materials in L2).  It
     // is taken when the flat pool is not (too few waves per CU beside a big sphere table) and >= 12 waves fit.
     const size_t scene_lds_g = kx::scene_lds_bytes_grid(c->n_spheres, hosek);
-    const bool grid_ok = pt && (!count || (p->flags & MIRT_FLAG_COUNT_GRID)) && c->grid_bytes != 0 && !(p->flags & MIRT_FLAG_NO_GRID);
+    const bool grid_ok = pt && (!count || ((p->flags & MIRT_FLAG_COUNT_GRID) && !frame_stream)) && c->grid_bytes != 0 &&
+                         !(p->flags & MIRT_FLAG_NO_GRID);
     // one 1024-thread block per CU; its path pools take what scene + grid leave of the block's LDS (counting launches:
     // the largest geometry only)
     const size_t lds_beside = scene_lds_g + c->grid_bytes;
@@ -664,7 +671,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const size_t lds_pool_grid_block = lds_beside + pcg.lds_bytes;
     const uint32_t pool_grid_waves_per_cu = pcg.slots ? (uint32_t)(c->lds_per_cu / lds_pool_grid_block) * (pcg.threads / 64u) : 0u;
     bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
-                     !(p->flags & MIRT_FLAG_KERNEL_STRIP) &&
+                     !(p->flags & MIRT_FLAG_KERNEL_STRIP) && !frame_stream &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
                       (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 16));
     if (tune.pool_grid == 0) pool_grid = false;
@@ -679,6 +686,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
     a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
     a.sample_begin = p->sample_begin;
+    a.frame_spp = pt ? p->frame_spp : 0u;
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     for (int q = 0; q < 5; ++q) a.queue_routine[q] = c->queue_routine[q];
@@ -733,6 +741,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // few samples per pixel (the reference's interactive loop adds 2 per frame): lane = pixel instead of lane = sample
     bool by_pixel = pt && !pool && !count && p->spp < mirt::kByPixelMaxSpp;
     if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
+    if (frame_stream) by_pixel = true;                    // also for counting launches (flat scan) and any spp
     a.static_units = 0;
     if (by_pixel) {
         a.n_units = (uint32_t)((npix + 63u) / 64u);
@@ -777,7 +786,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     } else {
         HIP_TRY(fast ? kf::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream) : kx::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
         snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
-                 tf[use_grid], tf[by_pixel && !count]);
+                 tf[use_grid], tf[by_pixel]);
     }
     HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
     if (d_accum) {                                   // resolve/read must see these sums whatever stream they were added on

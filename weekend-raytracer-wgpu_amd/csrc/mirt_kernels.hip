@@ -406,11 +406,16 @@ MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
 }
 
 // initRng (wgsl:498-502, frame = sample + 1) + samplePixel (wgsl:114-117) + cameraMakeRay (wgsl:456-478)
+// RESEED = false continues the caller's stream: the reference's samplePixel loop draws all samples of one frame from
+// the stream initRng seeded once for that frame (MirtParams.frame_spp > 0; lane-per-pixel schedule only).
+template <bool RESEED = true>
 MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x, uint32_t y, uint32_t sample,
                                Rng& rng, f3& ro, f3& rd)
 {
-    const uint32_t pixel_index = x + y * A.width;
-    rng.state = jenkins_hash((pixel_index ^ jenkins_hash(sample + 1u)) ^ A.seed_mix);
+    if constexpr (RESEED) {
+        const uint32_t pixel_index = x + y * A.width;
+        rng.state = jenkins_hash((pixel_index ^ jenkins_hash(sample + 1u)) ^ A.seed_mix);
+    }
     const float u = ((float)x + rng.next()) * C.inv_w;
     const float v = 1.0f - ((float)y + rng.next()) * C.inv_h;
     const float lr = sqrt_unit(rng.next());
@@ -1035,12 +1040,20 @@ __global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderAr
             const uint32_t x = (inside ? pi : 0u) - ci * A.width;
             const uint32_t y = abs_row(A, ci);
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
+            Rng rng;
+            rng.state = 0;
             for (uint32_t s = 0; s < A.spp; ++s) {
-                Rng rng;
                 f3 ro, rd;
                 {
                     const CamRegs C = load_camera(S, A);
-                    generate_primary(A, C, x, y, A.sample_begin + s, rng, ro, rd);
+                    const uint32_t sample = A.sample_begin + s;
+                    if (A.frame_spp == 0u) {
+                        generate_primary(A, C, x, y, sample, rng, ro, rd);
+                    } else {                     // the reference's stream: frame = sample / n + 1 seeds once, its n samples share it
+                        if (sample % A.frame_spp == 0u)
+                            rng.state = jenkins_hash(((x + y * A.width) ^ jenkins_hash(sample / A.frame_spp + 1u)) ^ A.seed_mix);
+                        generate_primary<false>(A, C, x, y, sample, rng, ro, rd);
+                    }
                 }
                 const f3 c = path_radiance<COUNT, HOSEK, GRID>(A, S, G, inside, rng, ro, rd, work, lane);
                 acc_r += to_fixed(c.x);
@@ -1636,6 +1649,8 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
 #else
     if (count && use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, true>, g, b, a, stream)
                                         : launch_with_lds(render_pt_strip_kernel<true, false, true>, g, b, a, stream);
+    if (count && by_pixel) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false, true>, g, b, a, stream)
+                                        : launch_with_lds(render_pt_strip_kernel<true, false, false, true>, g, b, a, stream);
     if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
                             : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
 #endif

@@ -453,8 +453,13 @@ class Layer:
 
 class Raytracer:
     def __init__(self, scene: Scene, render_params: RenderParams, *, device: int = 0,
-                 sky_state: Optional[_abi.MirtSkyState] = None):
+                 sky_state: Optional[_abi.MirtSkyState] = None, reference_stream: bool = False):
+        """`reference_stream=True` makes `render_frame` (and `render`) draw the samples of one frame from ONE RNG
+        stream per pixel, seeded with the frame number -- the reference's initRng / samplePixel (wgsl:498-502,
+        105-122) for `num_samples_per_pixel` samples per frame (MirtParams.frame_spp).  The default keeps one stream
+        per sample (frame_number = sample + 1), which does not depend on how samples are grouped into frames."""
         render_params.validate()                                   # mod.rs:44-47
+        self.reference_stream = reference_stream
         self.render_params = render_params
         self.material_data, self.global_texture_data = flatten_materials(scene.materials)   # mod.rs:160-183
         self.spheres = list(scene.spheres)
@@ -474,7 +479,8 @@ class Raytracer:
         if self.sky_state is not None:
             flags |= _abi.MIRT_FLAG_SKY_HOSEK
         return make_params(rp.viewport_size[0], rp.viewport_size[1], spp, mode=_abi.MIRT_MODE_PT,
-                           num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed)
+                           num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed,
+                           frame_spp=rp.sampling.num_samples_per_pixel if self.reference_stream else 0)
 
     def render_frame(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
         """`Raytracer::render_frame` (mod.rs:303-351) without the wgpu draw: add
