@@ -24,8 +24,9 @@ def ppms(tmp_path_factory):
             f.write(b"P6\n1024 512\n255\n")
             f.write(a.tobytes())
         out[name] = str(p)
-    if not DEMO.exists():
-        subprocess.run(["make", "-C", str(DEMO.parent)], check=True, capture_output=True)
+    # always through make (a no-op when up to date): a stale binary built against an older include/mirt.h passes wrongly
+    # sized structs across the ABI
+    subprocess.run(["make", "-C", str(DEMO.parent)], check=True, capture_output=True)
     return out
 
 
