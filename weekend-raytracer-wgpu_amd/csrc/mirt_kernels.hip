@@ -1186,7 +1186,6 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
     unsigned char* const L_ring = pool + Lay::kOffRing;
     uint32_t* const L_cell = reinterpret_cast<uint32_t*>(pool + Lay::kOffCell);
 
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     Work<COUNT> work;
     work.clear();
@@ -1376,6 +1375,23 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
                 bounce += 1;
             }
 
+#if defined(MIRT_PROBE_NOP) || defined(MIRT_PROBE_VALU8)
+            {   // fetch-bandwidth probes: 32 s_nop (4 bytes each, no execution unit) / 32 VALU adds with a 32-bit literal (8 bytes each)
+                float pv0 = thr.x;
+#ifdef MIRT_PROBE_NOP
+#pragma unroll
+                for (int i = 0; i < 32; ++i) asm volatile("s_nop 0");
+#endif
+#ifdef MIRT_PROBE_VALU8
+                float pa = thr.x, pb = thr.y, pc = thr.z, pd = rd.x;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("v_add_f32 %0, 0x3f8ccccd, %0\n v_add_f32 %1, 0x3f8ccccd, %1\n v_add_f32 %2, 0x3f8ccccd, %2\n v_add_f32 %3, 0x3f8ccccd, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
+                pv0 = pa + pb + pc + pd;
+#endif
+                asm volatile("" :: "v"(pv0));
+            }
+#endif
 #if defined(MIRT_PROBE_VALU) || defined(MIRT_PROBE_LDS) || defined(MIRT_PROBE_SALU) || defined(MIRT_PROBE_VALU_DEP)
             // Sensitivity probes (experiment builds only, tools/ab_libs.py): extra instructions of ONE class per step,
             // independent of the step's data, to measure what one more instruction of that class costs.
@@ -1471,7 +1487,9 @@ __global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArg
 #pragma unroll
             for (uint32_t k = 0; k < kNumOps; ++k) {
                 const unsigned long long mk_ = __ballot(new_op == k);
-                if (new_op == k) L_ring[k * RING + tail[k] + (uint32_t)__popcll(mk_ & lt_mask)] = (unsigned char)slot;
+                // rank among the lanes of this queue = set bits of the ballot below this lane: v_mbcnt_lo + v_mbcnt_hi
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_, 0u));
+                if (new_op == k) L_ring[k * RING + tail[k] + rank] = (unsigned char)slot;
                 tail[k] += (uint32_t)__popcll(mk_);
             }
         }
