@@ -111,7 +111,7 @@ def main() -> int:
               f"* routines alone: **{total['valu'] / 0.92:.0f} VALU per 64 samples** (fp {total['valu_fp'] / 0.92:.0f}, seeds {total['valu_seed'] / 0.92:.0f}, "
               f"int/logic {total['valu_int'] / 0.92:.0f}, compare+select {total['valu_cmp_select'] / 0.92:.0f}, convert {total['valu_convert'] / 0.92:.0f}, "
               f"moves {total['valu_move'] / 0.92:.0f});",
-              "* measured (`SQ_INSTS_VALU`, `profiles/r02e_c3_pmc_summary.json`): 665 VALU per 64 samples — the difference is the pool's own work",
+              "* measured (`SQ_INSTS_VALU`, `profiles/r02f_c3_pmc_summary.json`): 664 VALU per 64 samples — the difference is the pool's own work",
               "  (pick, pop, gather, unpack, pack, store, push: about 65 VALU per step that is not fast-forwarded) minus the out-of-line paths",
               "  that the static counts include;",
               "* algorithmic floating-point operations (SURVEY §8d): 284.6 flop per sample, i.e. between 142 (all fused) and 285 (none fused) fp",
