@@ -1,0 +1,48 @@
+"""bench.py end to end on the GPU (short runs): the ONE JSON line must carry the driver's contract fields, the roofline
+object, the kernel's own name and -- with the CPU legs on -- cpu_baseline and verified_rows that are all true."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"}
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_fields_and_a_verified_frame():
+    d = _bench("--steps", "2", "--warmup", "1")
+    assert CONTRACT <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "1000 spp" in d["metric"]
+    assert d["config"]["width"] == 1920 and d["config"]["spp"] == 1000 and "configs[2]" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["kernel"].startswith("render_pt_pool_kernel<") and r["peak"] == 157.3 and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["value"] - 1920 * 1080 * 1000 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.02                       # the kernel is the step
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert {"faithful_1_thread", "clean_1_thread", "faithful_all_cores", "clean_all_cores"} <= set(d["cpu_baseline"]["layer_rs"])
+    assert len(d["verified_rows"]) >= 4 and all(v["equal"] for v in d["verified_rows"])
+    assert d["fast_math"]["kernel"].startswith("fast_build::") and d["fast_math"]["within_1_pct"] >= 99.9
+
+
+@pytest.mark.parametrize("config,kernel", [("2", "render_pt_strip_kernel<"), ("parity", "render_parity_kernel<"), ("5", "render_pt_pool_kernel<1024,")])
+def test_other_configs_emit_the_same_shape(config, kernel):
+    d = _bench("--config", config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert CONTRACT <= set(d) and d["roofline"]["kernel"].startswith(kernel)
+    assert "cpu_baseline" not in d and "verified_rows" not in d
+    if config == "5":
+        assert d["roofline"]["grid_walk_lane_utilization"] > 0.5
