@@ -459,3 +459,27 @@ def test_raytracer_render_frame_with_the_reference_stream(oracle):
         img = rt.render_frame()
         assert_images_equal(img, oracle.render(sd, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2)), f"after {k} spp")
     rt.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MIRT_GRID_FUZZ_SEEDS", "10"))))      # deeper runs: MIRT_GRID_FUZZ_SEEDS=60
+def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
+    """Random soups of 32-700 spheres (0-3 big ones besides the ground, random cell sizes through the radii, random
+    cameras with and without aperture, 2-8 bounces): the pool kernel's grid build -- all three pool geometries occur
+    (152 / 128 / 96 slots, whichever fits LDS beside the blob), walks in instalments, one scatter queue -- the strip
+    kernel's grid build and the default choice must all give the oracle's flat-scan image exactly."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(32, 700))
+    spread = float(rng.uniform(0.5, 9.0))
+    spheres, gm, tex = _sphere_soup(rng, n, spread, 0.03, float(rng.uniform(0.1, 0.6)), n_big=int(rng.integers(0, 4)))
+    w, h, spp = 96, 54, int(rng.choice([48, 64, 100]))
+    cam = simple_camera(w, h, eye=tuple(rng.normal(size=3) * 4 + np.array([0, 3, 8])), direction=(float(rng.normal() * 0.3), -0.3, -1.0),
+                        vfov=float(rng.uniform(25, 70)), aperture=float(rng.choice([0.0, 0.3])), focus=8.0)
+    sd = m.SceneData(cam, spheres, gm, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=int(rng.integers(2, 9)), flags=LINEAR)
+    want = oracle.render(sd, p)
+    for fl in (0, m.MIRT_FLAG_KERNEL_POOL, m.MIRT_FLAG_KERNEL_STRIP):
+        p.flags = LINEAR | fl
+        assert_images_equal(gpu_ctx.render(p), want, f"seed {seed}: {n} spheres, flags {fl}, {gpu_ctx.last_kernel()}")
+        if fl == m.MIRT_FLAG_KERNEL_POOL:
+            assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and gpu_ctx.last_kernel().endswith(",1,true>")
