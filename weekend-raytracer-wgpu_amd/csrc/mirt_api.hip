@@ -645,13 +645,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const uint32_t pool_cfg = tune.pool_config >= 0 ? (uint32_t)tune.pool_config : mirt::kDefaultPoolConfig;
     const uint32_t pool_nq = kx::pool_scatter_queues(c->n_shading_routines, count);
     const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
-    // Default schedule: the pooled kernel pays off when paths diverge over >= 2 scatter routines,
-    // a strip holds enough samples to keep the pool full, and the pools still leave >= 16 waves
-    // per CU resident beside the scene tables (measured: 1 sphere 0.9x, 3 spheres 1.4x, 5 spheres
-    // 1.5x, 484 spheres 0.75x of the strip kernel).
+    // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
+    // pools still leave >= 16 waves per CU resident beside the scene tables.  Since fast-forwarding (round 2) that
+    // holds for single-routine scenes too -- paths still end at different depths, which the pool re-compacts --
+    // (single metal sphere, 1080p x 100 spp: 1.81 ms against the strip kernel's 2.27; 3 spheres 1.5x, 5 spheres 1.6x).
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
     const uint32_t pool_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_block ? lds_pool_block : 1)) * (pc.threads / 64u);
-    bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_waves_per_cu >= 16;
+    bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 1 && pool_waves_per_cu >= 16;
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
     // the reference's per-frame RNG stream makes a pixel's samples sequentially dependent: lane-per-pixel strip kernel only
@@ -673,7 +673,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
                      !(p->flags & MIRT_FLAG_KERNEL_STRIP) && !frame_stream &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
-                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 2 && pool_grid_waves_per_cu >= 16));
+                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 1 && pool_grid_waves_per_cu >= 16));
     if (tune.pool_grid == 0) pool_grid = false;
     if (pool_grid) pool = true;
     const mirt::PoolConfig pcu = pool_grid ? pcg : pc;                 // the geometry of the pool kernel that will run
