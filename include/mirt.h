@@ -148,7 +148,14 @@ enum {
      * v_log (about 1 ulp) and contraction instead of the bit-exact arithmetic.  Same RNG streams and exact integer
      * accumulation, so the image is deterministic, but pixels may differ from the default build by a few units in
      * the last place: NO parity claim holds with this flag.  Ignored by counting launches and in parity mode. */
-    MIRT_FLAG_FAST_MATH      = 1u << 8
+    MIRT_FLAG_FAST_MATH      = 1u << 8,
+    /* OPT-IN "LDS texel tiles" (BASELINE configs[3]): scenes with an image texture run the pooled kernel's tile build
+     * (render_pt_pool_tile_kernel): every wave keeps a 16 x 2 texel window of the texture in LDS, centred on the first
+     * image fetch of its strip, and serves the fetches that fall into it from there.  Same texel values, so the image
+     * is IDENTICAL to the default build's; measured 3 % slower on config 4, hence opt-in.  A hint: it has
+     * no effect where the pooled kernel does not run (few samples per pixel, many-sphere scenes, no image texture).
+     * With MIRT_FLAG_COUNT_WORK it fills MirtStats.texel_fetches / texel_tile_hits. */
+    MIRT_FLAG_TEXEL_TILES    = 1u << 9
 };
 
 /* What one render call computes.  The image is `width x height`; this call renders the rows
@@ -200,6 +207,8 @@ typedef struct MirtStats {
     uint64_t wave_iterations;  /* PT: bounce-loop iterations summed over waves (x64 = lane slots) */
     uint64_t grid_cells;       /* MIRT_FLAG_COUNT_GRID: grid cells visited, summed over lanes */
     uint64_t grid_wave_cells;  /* MIRT_FLAG_COUNT_GRID: cell-loop iterations summed over waves (x64 = lane slots) */
+    uint64_t texel_fetches[2];   /* MIRT_FLAG_TEXEL_TILES: image-texel fetches at [0] camera-ray hits, [1] later bounces */
+    uint64_t texel_tile_hits[2]; /* ... of those, served by the wave's LDS tile */
 } MirtStats;
 
 typedef enum MirtStatus {

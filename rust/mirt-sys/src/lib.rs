@@ -103,6 +103,7 @@ pub const MIRT_FLAG_KERNEL_POOL: u32 = 1 << 5;
 pub const MIRT_FLAG_NO_GRID: u32 = 1 << 6;
 pub const MIRT_FLAG_COUNT_GRID: u32 = 1 << 7;
 pub const MIRT_FLAG_FAST_MATH: u32 = 1 << 8;
+pub const MIRT_FLAG_TEXEL_TILES: u32 = 1 << 9;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -141,6 +142,8 @@ pub struct MirtStats {
     pub wave_iterations: u64,
     pub grid_cells: u64,
     pub grid_wave_cells: u64,
+    pub texel_fetches: [u64; 2],
+    pub texel_tile_hits: [u64; 2],
 }
 
 #[repr(C)]

@@ -7,7 +7,7 @@ gfx950 behind the C ABI of include/mirt.h); this package is the host-side mirror
 reference's Rust interface.  Import it as `weekend_raytracer_wgpu_amd` (repo-root shim).
 """
 from . import _abi
-from ._abi import (MIRT_FLAG_COUNT_GRID, MIRT_FLAG_COUNT_WORK, MIRT_FLAG_FAST_MATH, MIRT_FLAG_KERNEL_POOL, MIRT_FLAG_KERNEL_STRIP, MIRT_FLAG_NO_GRID, MIRT_FLAG_NO_SRGB, MIRT_FLAG_NO_TONEMAP, MIRT_FLAG_SKY_HOSEK,
+from ._abi import (MIRT_FLAG_COUNT_GRID, MIRT_FLAG_COUNT_WORK, MIRT_FLAG_FAST_MATH, MIRT_FLAG_KERNEL_POOL, MIRT_FLAG_KERNEL_STRIP, MIRT_FLAG_NO_GRID, MIRT_FLAG_NO_SRGB, MIRT_FLAG_NO_TONEMAP, MIRT_FLAG_SKY_HOSEK, MIRT_FLAG_TEXEL_TILES,
                    MIRT_MODE_PARITY, MIRT_MODE_PT)
 from ._lib import LIB_PATH, MirtError, lib
 from .context import Context, SceneData, make_params, params_out_row_index, params_out_rows

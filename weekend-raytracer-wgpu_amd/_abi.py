@@ -19,6 +19,7 @@ MIRT_FLAG_KERNEL_POOL = 1 << 5
 MIRT_FLAG_NO_GRID = 1 << 6
 MIRT_FLAG_COUNT_GRID = 1 << 7
 MIRT_FLAG_FAST_MATH = 1 << 8
+MIRT_FLAG_TEXEL_TILES = 1 << 9
 
 MIRT_OK = 0
 STATUS = {
@@ -107,7 +108,8 @@ class MirtStats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("roots", C.c_uint64), ("hits", C.c_uint64),
                 ("scatter", C.c_uint64 * 5), ("sky_misses", C.c_uint64),
                 ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
-                ("grid_cells", C.c_uint64), ("grid_wave_cells", C.c_uint64)]
+                ("grid_cells", C.c_uint64), ("grid_wave_cells", C.c_uint64),
+                ("texel_fetches", C.c_uint64 * 2), ("texel_tile_hits", C.c_uint64 * 2)]
 
     def as_dict(self) -> dict:
         return {"kernel_ms": self.kernel_ms, "kernel_ms_total": self.kernel_ms_total, "launches": self.launches,
@@ -115,7 +117,8 @@ class MirtStats(C.Structure):
                 "sphere_tests": self.sphere_tests, "roots": self.roots, "hits": self.hits,
                 "scatter": list(self.scatter), "sky_misses": self.sky_misses,
                 "lane_iterations": self.lane_iterations, "wave_iterations": self.wave_iterations,
-                "grid_cells": self.grid_cells, "grid_wave_cells": self.grid_wave_cells}
+                "grid_cells": self.grid_cells, "grid_wave_cells": self.grid_wave_cells,
+                "texel_fetches": list(self.texel_fetches), "texel_tile_hits": list(self.texel_tile_hits)}
 
 
 # every symbol include/mirt.h declares: name -> (restype, argtypes)

@@ -248,6 +248,7 @@ struct MirtContext {
     uint32_t n_spheres = 0, n_mats = 0;
     uint64_t n_texels = 0;
     bool     have_sky = false;
+    bool     has_image_texture = false;   // a material refers to a texture larger than 1x1
     uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
     uint32_t queue_routine[5] = {0, 1, 2, 3, 4};   // dense numbering of the routines present (pool kernel queues)
     int      pt_scene_status = MIRT_OK;
@@ -516,6 +517,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     }
     // PreparedMaterial: GpuMaterial + 1/x + the texel of every 1x1 texture (see mirt_kernels.h)
     std::vector<mirt::PreparedMaterial> pmats(s->n_materials);
+    std::vector<unsigned char> mat_has_image(s->n_materials, 0);     // a texture larger than 1x1: what MIRT_FLAG_TEXEL_TILES caches in LDS
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         const MirtMaterial& in = s->materials[i];
         mirt::PreparedMaterial& o = pmats[i];
@@ -533,6 +535,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
                 o.tex[k][2] = s->texels[3 * (size_t)off + 2];
                 std::memcpy(&o.tex[k][3], &off, 4);
             } else {
+                if ((uint64_t)w * h > 1u) mat_has_image[i] = 1;
                 std::memcpy(&o.tex[k][0], &w, 4);
                 std::memcpy(&o.tex[k][1], &h, 4);
                 std::memcpy(&o.tex[k][2], &off, 4);
@@ -571,6 +574,9 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     c->n_spheres = s->n_spheres;
     c->n_mats = s->n_materials;
     c->n_texels = s->n_texels;
+    c->has_image_texture = false;                // ... on a material some sphere uses
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (s->spheres[i].material_idx < s->n_materials && mat_has_image[s->spheres[i].material_idx]) c->has_image_texture = true;
     c->have_scene = true;
     return MIRT_OK;
 }
@@ -642,7 +648,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // kernel choice (path-traced mode): the pooled kernel needs enough samples per tile to keep
     // its path pool full, 8-bit bounce counters and room for the pool beside the scene in LDS
     const Tuning& tune = c->tuning;
-    const uint32_t pool_cfg = tune.pool_config >= 0 ? (uint32_t)tune.pool_config : mirt::kDefaultPoolConfig;
+    // MIRT_FLAG_TEXEL_TILES: flat scenes with an image texture run the pool geometry that keeps a texel window per wave
+    const bool tiles = pt && (p->flags & MIRT_FLAG_TEXEL_TILES) && c->has_image_texture && tune.pool_config < 0;
+    const uint32_t pool_cfg = tune.pool_config >= 0 ? (uint32_t)tune.pool_config : (tiles ? mirt::kTilePoolConfig : mirt::kDefaultPoolConfig);
     const uint32_t pool_nq = kx::pool_scatter_queues(c->n_shading_routines, count);
     const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
@@ -670,7 +678,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (count && pcg.slots != mirt::kGridPoolSlotChoices[0]) pcg.slots = 0;
     const size_t lds_pool_grid_block = lds_beside + pcg.lds_bytes;
     const uint32_t pool_grid_waves_per_cu = pcg.slots ? (uint32_t)(c->lds_per_cu / lds_pool_grid_block) * (pcg.threads / 64u) : 0u;
-    bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && pool_cfg == mirt::kDefaultPoolConfig && p->num_bounces <= 255u &&
+    bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && tune.pool_config < 0 && p->num_bounces <= 255u &&
                      !(p->flags & MIRT_FLAG_KERNEL_STRIP) && !frame_stream &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
                       (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 1 && pool_grid_waves_per_cu >= 16));
@@ -865,6 +873,10 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.wave_iterations = h[mirt::kCntWaveIters];
         c->stats.grid_cells = h[mirt::kCntCells];
         c->stats.grid_wave_cells = h[mirt::kCntWaveCells];
+        c->stats.texel_fetches[0] = h[mirt::kCntTexelsPrimary];
+        c->stats.texel_fetches[1] = h[mirt::kCntTexelsLater];
+        c->stats.texel_tile_hits[0] = h[mirt::kCntTileHitsPrimary];
+        c->stats.texel_tile_hits[1] = h[mirt::kCntTileHitsLater];
 #ifdef MIRT_PROBE_TEXELS
         c->stats.grid_cells = h[12]; c->stats.grid_wave_cells = h[13]; c->stats.lane_iterations = h[14]; c->stats.wave_iterations = h[15];
 #endif

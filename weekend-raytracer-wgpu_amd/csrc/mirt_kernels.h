@@ -68,11 +68,16 @@ constexpr uint32_t kGridMaxCells   = 8192;
 constexpr uint32_t kStripLevels   = 5;    // strip widths 16, 8, 4, 2, 1
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
-constexpr uint32_t kNumCounters   = 16;   // u64 work counters (MirtStats order)
+constexpr uint32_t kNumCounters   = 18;   // u64 work counters (MirtStats order)
 constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 KB per CU); sphere ids are 12 bit in the pool kernel
 
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
 constexpr uint32_t kDefaultPoolConfig = 0;
+// MIRT_FLAG_TEXEL_TILES: the pool geometry with an LDS texel window per wave (render_pt_pool_tile_kernel)
+#ifndef MIRT_TILE_SLOTS
+#define MIRT_TILE_SLOTS 112
+#endif
+constexpr uint32_t kTilePoolConfig = 5, kTilePoolSlots = MIRT_TILE_SLOTS;
 constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel
 // pool kernel, grid build (many-sphere scenes): ONE 1024-thread block per CU, so that the grid blob (~20 KB for RTIOW)
 // is staged once for all 16 waves and the rest of the 160 KB goes to the path pools.  Measured on RTIOW 1080p x 128 spp:
@@ -86,7 +91,9 @@ enum CounterSlot : uint32_t {
     kCntRays = 0, kCntTests, kCntRoots, kCntHits,
     kCntScatter0, kCntScatter1, kCntScatter2, kCntScatter3, kCntScatter4,
     kCntSky, kCntLaneIters, kCntWaveIters,
-    kCntCells, kCntWaveCells            // grid builds: cells visited by lanes / cell-loop iterations of waves
+    kCntCells, kCntWaveCells,           // grid builds: cells visited by lanes / cell-loop iterations of waves
+    kCntTexelsPrimary, kCntTileHitsPrimary,   // tile build: image-texel fetches of camera-ray hits / of those, served by the LDS tile
+    kCntTexelsLater, kCntTileHitsLater        // ... of later bounces
 };
 
 struct RenderArgs {

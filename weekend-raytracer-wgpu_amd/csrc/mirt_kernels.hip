@@ -144,8 +144,43 @@ MIRT_DEV f3 texel_at(const RenderArgs& A_unused, uint64_t g)
     return mk(e[0], e[1], e[2]);
 }
 
+// LDS texel tile of the pool kernel's tile build (MIRT_FLAG_TEXEL_TILES; BASELINE configs[3] "LDS texel tiles"): a
+// kTileW x kTileH window of ONE image texture per wave and strip, in three colour planes, centred on the texel of the
+// strip's first image fetch -- the camera rays of a strip hit neighbouring texels (a 16-pixel strip of config 4 covers
+// about 9 x 2 texels at the centre of the earth sphere, more towards the limb), later bounces do not.  Lanes whose texel
+// lies in the window read LDS, the others the global table: the VALUES are the same, so the image cannot change.
+// Geometry, measured on config 4 (tools/texel_tiles.py, profiles/r02_texel_tile_build.json): the window has to fit
+// beside the pool in the 6.6 KB a wave has at 6 blocks per CU, and slots are worth more than texels --
+//   88 slots + 32 x 4 texels: camera-ray hits 97.6 % from the tile, all fetches 77 %, kernel time +11.4 % vs the default build
+//  104 slots + 16 x 4:        92.3 % / 73 %, +5.1 %
+//  112 slots + 16 x 2:        83.9 % / 66 %, +3.1 %   <- built (the default build's pool, window in the spare LDS)
+#ifndef MIRT_TILE_W
+#define MIRT_TILE_W 16
+#endif
+#ifndef MIRT_TILE_H
+#define MIRT_TILE_H 2
+#endif
+constexpr uint32_t kTileW = MIRT_TILE_W, kTileH = MIRT_TILE_H, kTileTexels = kTileW * kTileH;
+constexpr uint32_t kTileBytes = 16 + kTileTexels * 12;      // header {j0, i0, table offset, texture width (0 = empty)} + planes
+struct TexelTile {
+    uint32_t* hdr;          // LDS, wave-private: where the lanes that place the window publish it
+    float*    plane;        // LDS [3][kTileTexels]
+    uint32_t  j0, i0, off, w;          // the window, wave-uniform registers (w == 0: none yet); see refresh()
+    uint32_t  fetched, from_tile;      // per lane, counting builds: image-texel fetches of the current routine / served by the tile
+    MIRT_DEV void reset(uint32_t lane) { if (lane == 0) *reinterpret_cast<uint4*>(hdr) = make_uint4(0u, 0u, 0u, 0u); j0 = i0 = off = w = 0u; }
+    // The window is placed inside a divergent region (by the lanes that fetch), so it reaches the wave's scalar registers
+    // through LDS: the pool kernel calls this in uniform control flow after every scatter routine until a window exists.
+    MIRT_DEV void refresh()
+    {
+        if (w != 0u) return;
+        const uint4 h = *reinterpret_cast<const uint4*>(hdr);
+        j0 = __builtin_amdgcn_readfirstlane(h.x); i0 = __builtin_amdgcn_readfirstlane(h.y);
+        off = __builtin_amdgcn_readfirstlane(h.z); w = __builtin_amdgcn_readfirstlane(h.w);
+    }
+};
+
 // texture_lookup (mod.rs:1000-1019 == wgsl:377-387); final index clamped to the table.
-MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height, uint32_t offset, float u, float v)
+MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height, uint32_t offset, float u, float v, TexelTile* T = nullptr)
 {
     const float uc = clamp01(u);
     const float vf = 1.0f - clamp01(v);
@@ -155,7 +190,42 @@ MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height,
 #ifdef MIRT_PROBE_NOFETCH    // experiment: the whole lookup EXCEPT the memory access -> the ceiling of any texel cache
     return mk(from_bits(0x3e800000u | (idx & 1u)), 0.4f, 0.5f);
 #else
-    return texel_at(A, (uint64_t)offset + (uint64_t)idx);
+    if (T == nullptr) return texel_at(A, (uint64_t)offset + (uint64_t)idx);
+    // ---- tile build: runs in the lanes of a wave that need an image texel (a divergent region) ----
+    uint4 hd = make_uint4(T->j0, T->i0, T->off, T->w);                          // scalar registers
+    if (T->w == 0u) {
+        // first image fetch of this strip: centre the window on the first lane's texel and load it with the lanes at hand
+        const uint32_t wf = __builtin_amdgcn_readfirstlane(width), hf = __builtin_amdgcn_readfirstlane(height);
+        const uint32_t of = __builtin_amdgcn_readfirstlane(offset);
+        if (wf >= kTileW && hf >= kTileH) {
+            const uint32_t jf = __builtin_amdgcn_readfirstlane(j), i_f = __builtin_amdgcn_readfirstlane(i);
+            uint32_t j0 = jf > kTileW / 2 ? jf - kTileW / 2 : 0u, i0 = i_f > kTileH / 2 ? i_f - kTileH / 2 : 0u;
+            j0 = j0 > wf - kTileW ? wf - kTileW : j0;
+            i0 = i0 > hf - kTileH ? hf - kTileH : i0;
+            const unsigned long long act = __ballot(true);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+            const uint32_t n_act = (uint32_t)__popcll(act);
+            for (uint32_t t = rank; t < kTileTexels; t += n_act) {
+                const f3 e = texel_at(A, (uint64_t)of + (uint64_t)((i0 + t / kTileW) * wf + j0 + t % kTileW));
+                T->plane[t] = e.x; T->plane[kTileTexels + t] = e.y; T->plane[2 * kTileTexels + t] = e.z;
+            }
+            hd = make_uint4(j0, i0, of, wf);
+            if (rank == 0u) *reinterpret_cast<uint4*>(T->hdr) = hd;
+            __builtin_amdgcn_wave_barrier();       // LDS serves a wave's requests in order: the reads below see the planes
+        }
+    }
+    const uint32_t dj = j - hd.x, di = i - hd.y;
+    const bool in = (hd.w != 0u) & (hd.w == width) & (hd.z == offset) & (dj < kTileW) & (di < kTileH);
+    T->fetched += 1u;
+    T->from_tile += in ? 1u : 0u;
+    f3 c = mk(0, 0, 0);
+    if (__ballot(in) != 0ull) {
+        if (in) { const uint32_t t = di * kTileW + dj; c = mk(T->plane[t], T->plane[kTileTexels + t], T->plane[2 * kTileTexels + t]); }
+    }
+    if (__ballot(!in) != 0ull) {
+        if (!in) c = texel_at(A, (uint64_t)offset + (uint64_t)idx);
+    }
+    return c;
 #endif
 }
 
@@ -779,7 +849,7 @@ MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 // n.x < 0 and |n.z| <= ~5e-7 |n.x|; 1-v reaches 1.0 only for acos(-n.y) < 1e-7, i.e. n.y <= -1.
 // The guards below are 20x / 1e-6 wider than that (and false for NaN), and the rare lanes they
 // catch run the full formula.
-MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n)
+MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, TexelTile* T = nullptr)
 {
     const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[k][0]);    // one ds_read_b128 (m lives in LDS)
     const bool one = (m->flags >> k) & 1u;
@@ -797,14 +867,14 @@ MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 
             const uint32_t w = one ? 1u : bits(t4.x);
             const uint32_t h = one ? 1u : bits(t4.y);
             const uint32_t off = one ? bits(t4.w) : bits(t4.z);
-            c = texture_lookup(A, w, h, off, u, v);
+            c = texture_lookup(A, w, h, off, u, v, T);
         }
     }
     return c;
 }
 
 // scatterLambertian (wgsl:204-242): cosine-weighted direction around n through the Pixar ONB
-MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, Rng& rng, f3& dir, f3& atten)
+MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, Rng& rng, f3& dir, f3& atten, TexelTile* T = nullptr)
 {
     const float phi = rng.next_scaled(kTwoPi * 0x1p-32f);      // 2 pi r1 (r1 is used nowhere else)
     const float r2 = rng.next();
@@ -829,7 +899,7 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
         asm volatile("; scatter_lambertian: grazing direction" ::);
         if (grazing) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
     }
-    atten = albedo_at(A, m, k, n);
+    atten = albedo_at(A, m, k, n, T);
     if (__builtin_expect(__ballot(grazing) != 0ull, 0)) {      // kk == 1.0f elsewhere, and 1.0f * x == x
         asm volatile("; scatter_lambertian: grazing attenuation" ::);
         atten = kk * atten;
@@ -839,17 +909,17 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
 
 // The five scatter routines of scatterRay (wgsl:174-314), one function each so that the pool
 // kernel can run exactly one of them per wave.  rd = incoming direction, hp/hn = hit point/normal.
-MIRT_DEV void shade_lambertian(const RenderArgs& A, const PreparedMaterial* m, f3 hn, Rng& rng, f3& ndir, f3& att)
+MIRT_DEV void shade_lambertian(const RenderArgs& A, const PreparedMaterial* m, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {
-    scatter_lambertian(A, m, 0, hn, rng, ndir, att);
+    scatter_lambertian(A, m, 0, hn, rng, ndir, att, T);
 }
 
-MIRT_DEV void shade_metal(const RenderArgs& A, const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
+MIRT_DEV void shade_metal(const RenderArgs& A, const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {   // scatterMetal wgsl:244-248
     const f3 refl = reflect3(rd, hn);
     const f3 rs = rand_in_unit_sphere(rng);
     ndir = fma3(m->x, rs, refl);
-    att = albedo_at(A, m, 0, hn);
+    att = albedo_at(A, m, 0, hn, T);
 }
 
 MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
@@ -875,10 +945,10 @@ MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng
     att = mk(1, 1, 1);
 }
 
-MIRT_DEV void shade_checkerboard(const RenderArgs& A, const PreparedMaterial* m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att)
+MIRT_DEV void shade_checkerboard(const RenderArgs& A, const PreparedMaterial* m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {   // scatterCheckerboard wgsl:300-307: sign of sin(5x)sin(5y)sin(5z) from the signs of the factors
     const bool negative = sin_product_negative(5.0f * hp.x, 5.0f * hp.y, 5.0f * hp.z);
-    scatter_lambertian(A, m, negative ? 0 : 1, hn, rng, ndir, att);
+    scatter_lambertian(A, m, negative ? 0 : 1, hn, rng, ndir, att, T);
 }
 
 MIRT_DEV void shade_missing(f3 hn, Rng& rng, f3& ndir, f3& att)
@@ -1151,7 +1221,7 @@ constexpr uint32_t kWalkCellsFresh = MIRT_WALK_FRESH, kWalkCellsResume = MIRT_WA
 // accumulators, the item counter and all queue depths in SGPRs.  Nothing is shared between waves after the
 // scene has been staged: no barrier, no inter-wave atomic.  (A block-level pool with barriers was measured
 // 20 % slower)
-template <uint32_t SLOTS, uint32_t NQ, bool GRID = false>
+template <uint32_t SLOTS, uint32_t NQ, bool GRID = false, bool TILE = false>
 struct WavePoolLayout {
     static constexpr uint32_t kQueues   = NQ + 1 + (GRID ? 1 : 0);            // scatter queues, OP_GEN, and OP_WALK in grid builds
     static constexpr uint32_t kRing     = SLOTS;                              // per-queue stack capacity: every slot could sit in one queue
@@ -1159,356 +1229,23 @@ struct WavePoolLayout {
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
     static constexpr uint32_t kOffCell  = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32: grid cell of a path whose walk is cut (GRID)
     static constexpr uint32_t kOffRing  = kOffCell + (GRID ? SLOTS * 4 : 0);  // [kQueues][kRing] u8
-    static constexpr uint32_t kBytes    = ((kOffRing + kQueues * kRing + 15) / 16) * 16;
+    static constexpr uint32_t kOffTile  = ((kOffRing + kQueues * kRing + 15) / 16) * 16;     // TexelTile: header + 3 colour planes (TILE)
+    static constexpr uint32_t kBytes    = kOffTile + (TILE ? ((kTileBytes + 15) / 16) * 16 : 0);
 };
 
 // GRID = true (many-sphere scenes): nearest hit through the uniform grid staged behind the spheres; the material
 // table stays in global memory / L2 as in the strip kernel's grid build, and the pools follow the grid in LDS.
-template <uint32_t THREADS, uint32_t SLOTS, uint32_t MINW, bool COUNT, bool HOSEK, uint32_t NQ = 5, bool GRID = false>
-__global__ __launch_bounds__(THREADS, MINW) void render_pt_pool_kernel(RenderArgs A)
-{
-    using Lay = WavePoolLayout<SLOTS, NQ, GRID>;
-    constexpr uint32_t OP_GEN = NQ, OP_WALK = NQ + 1, kNumOps = Lay::kQueues;
-    static_assert(NQ >= 1 && NQ < kMaxQueues, "scatter queues");
-    constexpr uint32_t RING = Lay::kRing;
-    static_assert(SLOTS >= 64 && SLOTS <= 256 && SLOTS % 8 == 0, "slot ids are 8 bit");
-    extern __shared__ __align__(16) unsigned char smem[];
-    const SceneLds S = stage_scene<true, !GRID>(A, smem, HOSEK);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint32_t scene_bytes = (uint32_t)scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, !GRID);
-    GridLds G{};
-    if constexpr (GRID) { G = stage_grid(A, smem + scene_bytes); scene_bytes += A.grid_bytes; }
-    unsigned char* pool = smem + scene_bytes + wave * Lay::kBytes;
-    uint4* const L_state = reinterpret_cast<uint4*>(pool + Lay::kOffState);
-    unsigned long long* const L_acc = reinterpret_cast<unsigned long long*>(pool + Lay::kOffAcc);
-    unsigned char* const L_ring = pool + Lay::kOffRing;
-    uint32_t* const L_cell = reinterpret_cast<uint32_t*>(pool + Lay::kOffCell);
-
-
-    Work<COUNT> work;
-    work.clear();
-
-    for (uint32_t strip = first_unit(); strip < A.n_units; strip = next_unit(A, lane)) {
-        // which level does this unit belong to?  (wave-uniform scalar code, once per strip)
-        const RenderArgs& AP = per_strip_args();         // the arguments this prologue needs, loaded here and now
-        uint32_t lvl = 0;
-#pragma unroll
-        for (uint32_t l = 1; l < kStripLevels; ++l) lvl = (strip >= AP.lvl_unit[l]) ? l : lvl;
-        uint32_t unit0 = AP.lvl_unit[0], pix0 = AP.lvl_pix[0], pix_end = AP.lvl_pix[1];
-#pragma unroll
-        for (uint32_t l = 1; l < kStripLevels; ++l)
-            if (lvl == l) { unit0 = AP.lvl_unit[l]; pix0 = AP.lvl_pix[l]; pix_end = AP.lvl_pix[l + 1]; }
-        const uint32_t width_log2 = 4u - lvl;              // 16, 8, 4, 2, 1 pixels
-        const uint32_t base_pix = pix0 + ((strip - unit0) << width_log2);
-        const uint32_t want_pixels = 1u << width_log2;
-        const uint32_t strip_pixels = (pix_end - base_pix < want_pixels) ? (pix_end - base_pix) : want_pixels;
-        const uint32_t total_items = strip_pixels * AP.spp;
-        // scalar (per-strip) pixel addressing: one division here instead of two per work item
-        const uint32_t base_ci = base_pix / AP.width;
-        const uint32_t base_x = base_pix - base_ci * AP.width;
-        const bool wide = AP.width >= kStripPixels;           // a strip then spans at most two rows
-        const uint32_t row0 = abs_row(AP, base_ci);
-        const uint32_t row1 = (base_ci + 1 < AP.out_rows) ? abs_row(AP, base_ci + 1) : row0;
-
-        // all slots start in the OP_GEN queue
-        for (uint32_t s = lane; s < SLOTS; s += 64) { L_ring[OP_GEN * RING + s] = (unsigned char)s; L_state[s * 3].w = 0u; }
-        if (lane < kStripPixels * 3) L_acc[lane] = 0ull;
-        // Each queue is a STACK of slot ids (order of service is free: the image does not depend on it), so a
-        // queue is described by its depth alone -- NQ + 1 SGPRs, no heads, no index wrap.
-        uint32_t tail[kNumOps];                            // wave-uniform (SGPRs)
-#pragma unroll
-        for (uint32_t k = 0; k < kNumOps; ++k) tail[k] = (k == OP_GEN) ? SLOTS : 0u;
-        uint32_t next_item = 0;
-
-        // Loop-carried path state of the lanes (registers).  A normal step loads it from the wave's pool (pick a queue,
-        // pop slot ids, gather); a FAST-FORWARD step inherits it from the step before: when every lane of a step moves
-        // on to the SAME routine (coherent primary rays all hitting the ground, sky pixels going straight back to OP_GEN:
-        // 43 % of all steps on config 3), storing the paths, pushing, picking, popping and gathering them again would
-        // only move the same 64 paths through LDS, so the wave runs that routine on them right away.  The order in
-        // which paths are served is free (exact integer accumulation), so the image cannot change.
-        bool ff = false;                                   // wave-uniform
-        uint32_t my_k = 0, my_n = 0;                       // wave-uniform: routine of this step, number of paths
-        uint32_t slot = 0, pix = 0, bounce = 0, missf = 0;
-        int best = 0;
-        float walk_closest = kMaxT;                        // GRID: state of a path whose grid walk is cut (OP_WALK)
-        uint32_t walk_cell = 0;
-        f3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), thr = mk(0, 0, 0);
-        Rng rng;
-        rng.state = 0;
-
-        for (;;) {
-            if (!ff) {
-                // ---- pick the deepest queue: max over keys depth << 3 | (7 - op); ties go to the lower op ----
-                uint32_t key = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < kNumOps; ++k) {
-                    const uint32_t kk = (tail[k] << 3) | (7u - k);
-                    key = (kk > key) ? kk : key;
-                }
-                const uint32_t depth = key >> 3;
-                if (depth == 0) break;                     // every queue empty: strip finished
-                my_k = 7u - (key & 7u);
-                my_n = (depth > 64u) ? 64u : depth;
-                const uint32_t my_begin = depth - my_n;    // the top my_n entries
-#pragma unroll
-                for (uint32_t k = 0; k < kNumOps; ++k) {
-                    tail[k] -= (my_k == k) ? my_n : 0u;
-                }
-
-                // ---- pop + gather ----
-                const bool has0 = lane < my_n;
-                slot = has0 ? (uint32_t)L_ring[my_k * RING + my_begin + lane] : 0u;
-                const uint4 q0 = L_state[slot * 3 + 0], q1 = L_state[slot * 3 + 1], q2 = L_state[slot * 3 + 2];
-                const uint32_t fl = q0.w;
-                ro = mk(from_bits(q0.x), from_bits(q0.y), from_bits(q0.z));      // the hit point for scatter steps
-                rd = mk(from_bits(q1.x), from_bits(q1.y), from_bits(q1.z));
-                best = has0 ? (int)(fl & 0xfffu) : 0;
-                if constexpr (GRID) {
-                    if (my_k == OP_WALK) {                 // a cut walk: nearest hit so far (none: bit 25) and the cell to resume in
-                        best = (fl >> 25) & 1u ? best : -1;
-                        walk_closest = from_bits(q2.w);
-                        walk_cell = L_cell[slot];
-                    }
-                }
-                thr = mk(from_bits(q2.x), from_bits(q2.y), from_bits(q2.z));
-                rng.state = q1.w;
-                pix = (fl >> 12) & 0xfu;
-                bounce = (fl >> 16) & 0xffu;
-                missf = (fl >> 24) & 1u;
-            }
-            const bool has = lane < my_n;
-            bool alive = has;
-            if constexpr (COUNT) { if (lane == 0) work.add(kCntWaveIters); }
-
-            if (my_k == OP_GEN) {
-                // finish the previous path of this slot ...
-                if (has && missf) {
-                    work.add(kCntSky);
-                    const f3 c = sky_color<HOSEK>(S, rd);
-                    atomicAdd(&L_acc[pix * 3 + 0], (unsigned long long)to_fixed(thr.x * c.x));
-                    atomicAdd(&L_acc[pix * 3 + 1], (unsigned long long)to_fixed(thr.y * c.y));
-                    atomicAdd(&L_acc[pix * 3 + 2], (unsigned long long)to_fixed(thr.z * c.z));
-                }
-                // ... and start the next work item in it
-                const uint32_t item = next_item + lane;
-                next_item += my_n;
-                alive = has && item < total_items;
-                uint32_t sample;
-                if (strip_pixels == want_pixels) { sample = item >> width_log2; pix = item & (want_pixels - 1u); }
-                else { sample = item / strip_pixels; pix = item - sample * strip_pixels; }      // ragged last strip
-                // pixel -> (x, y): the strip starts at (base_x, row0) and may wrap into following rows
-                uint32_t x = base_x + pix, y = row0;
-                if (wide) { if (x >= A.width) { x -= A.width; y = row1; } }
-                else { const uint32_t pi = base_pix + pix; const uint32_t ci = pi / A.width; x = pi - ci * A.width; y = abs_row(A, ci); }
-                // camera constants are (re)read from LDS here, 6 broadcast ds_read_b128 per GEN step, instead of
-                // living in 21 VGPRs across the whole kernel: the kernel then fits 6 waves per SIMD
-                const CamRegs C = load_camera(S, A);
-                generate_primary(A, C, x, y, A.sample_begin + sample, rng, ro, rd);
-                thr = mk(1, 1, 1);
-                bounce = 0;
-            } else if (GRID && my_k == OP_WALK) {
-                // nothing to shade: the tail below resumes these paths' grid walks
-            } else {
-                // sphereIntersection wgsl:431-440, then ONE scatter routine for the whole wave
-                PreparedSphere sp;
-                if constexpr (GRID) sp = A.spheres[best];  // grid builds keep no sphere table in LDS: one global read per hit
-                else sp = S.spheres[best];
-                const f3 hp = ro;                          // computed by the tail of the step that found the hit
-                const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
-                const PreparedMaterial* m = &S.pmats[has ? sp.material_idx : 0u];
-                f3 ndir = rd, att = mk(1, 1, 1);
-                // lanes without a slot run the routine too, on slot 0's (valid) state: their results are never
-                // stored, and leaving them in saves an exec-mask region around every routine
-                uint32_t routine = A.queue_routine[0];     // wave-uniform dispatch
-#pragma unroll
-                for (uint32_t k = 1; k < NQ; ++k) routine = (my_k == k) ? A.queue_routine[k] : routine;
-                // Grid builds (many-sphere scenes) keep ONE scatter queue and switch on the material per lane: there the
-                // trace -- grid set-up, big spheres, cell walk -- is 70 % of a step and shading the smaller part, so fuller
-                // steps (3 queues share the slots instead of 5) are worth more than undivided routines: -7 % on RTIOW.
-                if constexpr (GRID) {
-                    switch (m->id) {
-                    case 0u: if (has) work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
-                    case 1u: if (has) work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
-                    case 2u: if (has) work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
-                    case 3u: if (has) work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
-                    default: if (has) work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
-                    }
-                } else
-                if (routine == RT_LAMBERTIAN) {
-                    if (has) work.add(kCntScatter0);
-                    shade_lambertian(A, m, hn, rng, ndir, att);
-                } else if (routine == RT_METAL) {
-                    if (has) work.add(kCntScatter1);
-                    shade_metal(A, m, rd, hn, rng, ndir, att);
-                } else if (routine == RT_DIELECTRIC) {
-                    if (has) work.add(kCntScatter2);
-                    shade_dielectric(m, rd, hn, rng, ndir, att);
-                } else if (routine == RT_CHECKER) {
-                    if (has) work.add(kCntScatter3);
-                    shade_checkerboard(A, m, hp, hn, rng, ndir, att);
-                } else {
-                    if (has) work.add(kCntScatter4);
-                    shade_missing(hn, rng, ndir, att);
-                }
-#ifdef MIRT_PROBE_TEXELS    // experiment (tools/texel_probe.py): would a 64 x 32 texel tile per wave serve the texture fetches?
-                if constexpr (COUNT) {
-                    // lanes whose albedo comes from an image texture (texture 0 of a lambertian / metal material, not 1 x 1)
-                    const bool tex = has && !(m->flags & 1u) && (routine == RT_LAMBERTIAN || routine == RT_METAL);
-                    const unsigned long long tmask = __ballot(tex);
-                    if (tmask) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[0][0]);
-                        const uint32_t tw = bits(t4.x), th = bits(t4.y);
-                        const float u = (0.5f * kFrac1Pi) * (atan2_(-hn.z, hn.x) + kPi), v = kFrac1Pi * acos_(-hn.y);
-                        const uint32_t j = sat_u32(clamp01(u) * (float)tw), i = sat_u32((1.0f - clamp01(v)) * (float)th);
-                        const uint32_t tile = tex ? ((i >> 5) << 16) | (j >> 6) : 0xffffffffu;       // 64 x 32 texel tiles
-                        const uint32_t ref = __builtin_amdgcn_readlane(tile, __builtin_ctzll(tmask));   // the tile the first fetch would load
-                        const bool primary = bounce == 0u;         // first scatter of the path = the camera ray's hit
-                        if (tex) { work.add(primary ? 12 : 14); if (tile == ref) work.add(primary ? 13 : 15); }
-                    }
-                }
-#endif
-                ro = hp;
-                rd = ndir;
-                thr = thr * att;
-                bounce += 1;
-            }
-
-#if defined(MIRT_PROBE_NOP) || defined(MIRT_PROBE_VALU8)
-            {   // fetch-bandwidth probes: 32 s_nop (4 bytes each, no execution unit) / 32 VALU adds with a 32-bit literal (8 bytes each)
-                float pv0 = thr.x;
-#ifdef MIRT_PROBE_NOP
-#pragma unroll
-                for (int i = 0; i < 32; ++i) asm volatile("s_nop 0");
-#endif
-#ifdef MIRT_PROBE_VALU8
-                float pa = thr.x, pb = thr.y, pc = thr.z, pd = rd.x;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    asm volatile("v_add_f32 %0, 0x3f8ccccd, %0\n v_add_f32 %1, 0x3f8ccccd, %1\n v_add_f32 %2, 0x3f8ccccd, %2\n v_add_f32 %3, 0x3f8ccccd, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
-                pv0 = pa + pb + pc + pd;
-#endif
-                asm volatile("" :: "v"(pv0));
-            }
-#endif
-#if defined(MIRT_PROBE_VALU) || defined(MIRT_PROBE_LDS) || defined(MIRT_PROBE_SALU) || defined(MIRT_PROBE_VALU_DEP)
-            // Sensitivity probes (experiment builds only, tools/ab_libs.py): extra instructions of ONE class per step,
-            // independent of the step's data, to measure what one more instruction of that class costs.
-            {
-                float pv0 = thr.x, pv1 = thr.y, pv2 = thr.z;
-#ifdef MIRT_PROBE_VALU          // 32 independent full-rate VALU ops
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    asm volatile("v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %2, 1.0, %2\n v_mul_f32 %3, %0, %1" : "+v"(pv0), "+v"(pv1), "+v"(pv2), "=v"(pv0) : );
-#endif
-#ifdef MIRT_PROBE_VALU_DEP      // 32 VALU ops in ONE dependent chain
-#pragma unroll
-                for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pv0));
-#endif
-#ifdef MIRT_PROBE_LDS           // 4 broadcast ds_read_b128 of the scene (conflict-free)
-                {
-                    uint4 t0, t1, t2, t3;
-                    const uint32_t a0 = 0;
-                    asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)"
-                                 : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : "v"(a0) : "memory");
-                    pv1 = from_bits(t0.x ^ t1.x ^ t2.x ^ t3.x);
-                }
-#endif
-#ifdef MIRT_PROBE_SALU          // 32 SALU ops
-                {
-                    uint32_t sv = 1u;
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sv) : : "scc");
-                    if (sv == 0xdeadbeefu) pv2 = 0.0f;
-                }
-#endif
-                asm volatile("" :: "v"(pv0), "v"(pv1), "v"(pv2));
-            }
-#endif
-            // common tail: bounce limit (wgsl:130), nearest hit, classification
-            const bool resume = GRID && my_k == OP_WALK;   // wave-uniform
-            const bool trace = alive && (resume || bounce < A.num_bounces);
-            if constexpr (COUNT) { if (trace && !resume) work.add(kCntLaneIters); }
-            float closest;
-            int nb;
-            bool cut = false;                              // GRID: the walk used up its cell budget: continue in an OP_WALK step
-            if constexpr (GRID) {
-                closest = walk_closest;
-                nb = best;
-                grid_walk<COUNT>(S, G, ro, rd, trace, resume, resume ? kWalkCellsResume : kWalkCellsFresh, closest, nb, walk_cell, cut, work, lane);
-            } else {
-                nb = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, trace, closest, work);
-            }
-            const bool hit = trace && !cut && nb >= 0;
-            if (hit) work.add(kCntHits);
-            const uint32_t miss = (trace && !cut && nb < 0) ? 1u : 0u;        // left the scene: OP_GEN adds throughput x sky
-            // rayPointAtParameter (wgsl:442-444); unused after a miss; a cut walk keeps the ray's origin instead
-            const f3 hp = cut ? ro : fma3(closest, rd, ro);
-            // next routine, branch-free: the queue of a sphere's routine is kept with the sphere.  OP_GEN also when
-            // the bounce limit ended the path.
-            uint32_t hit_op;
-            if constexpr (GRID) hit_op = 0u;              // the one scatter queue of a grid build
-            else hit_op = S.spheres[hit ? nb : 0].op;
-            const uint32_t new_op = alive ? (cut ? OP_WALK : (hit ? hit_op : OP_GEN)) : OP_NONE;
-
-            // ---- fast-forward: all paths of this step wait for ONE routine -> run it on them now ----
-            if constexpr (kFastForwardMin <= 64u) {
-                const uint32_t k2 = __builtin_amdgcn_readfirstlane(new_op);      // lane 0 always holds a path (my_n >= 1)
-                if (k2 != OP_NONE && my_n >= kFastForwardMin && __ballot(has && new_op != k2) == 0ull) {
-                    ff = true;
-                    my_k = k2;
-                    ro = hp;
-                    if constexpr (GRID) { best = (k2 == OP_WALK) ? nb : (nb < 0 ? 0 : nb); walk_closest = closest; }
-                    else best = nb < 0 ? 0 : nb;
-                    missf = miss;
-                    continue;
-                }
-                ff = false;
-            }
-
-            if (has) {
-                const uint32_t packed = (uint32_t)(nb < 0 ? 0 : nb) | (pix << 12) | (bounce << 16) | (miss << 24) | ((nb >= 0 ? 1u : 0u) << 25);
-                L_state[slot * 3 + 0] = make_uint4(bits(hp.x), bits(hp.y), bits(hp.z), packed);
-                L_state[slot * 3 + 1] = make_uint4(bits(rd.x), bits(rd.y), bits(rd.z), rng.state);
-                L_state[slot * 3 + 2] = make_uint4(bits(thr.x), bits(thr.y), bits(thr.z), GRID ? bits(closest) : 0u);
-                if constexpr (GRID) { if (cut) L_cell[slot] = walk_cell; }
-            }
-#ifdef MIRT_PROBE_UNIFORM_NEXT   // experiment: how often do all lanes of a step move on to ONE routine?
-            if constexpr (COUNT) {
-                const unsigned long long act = __ballot(new_op != OP_NONE);
-                const uint32_t first_op = __builtin_amdgcn_readfirstlane(new_op);
-                const bool uniform = act != 0ull && __ballot(new_op == first_op) == act && (act & 1ull);
-                if (lane == 0) { work.add(14, uniform ? 1u : 0u); work.add(15, (uniform && __popcll(act) >= 56) ? 1u : 0u);
-                                 work.add(12, (uniform && first_op == OP_GEN) ? 1u : 0u); work.add(13, __popcll(act) >= 56 ? 1u : 0u); }
-            }
-#endif
-            // push every slot id to the queue of its next op (tails live in SGPRs: no atomics)
-#pragma unroll
-            for (uint32_t k = 0; k < kNumOps; ++k) {
-                const unsigned long long mk_ = __ballot(new_op == k);
-                // rank among the lanes of this queue = set bits of the ballot below this lane: v_mbcnt_lo + v_mbcnt_hi
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk_, 0u));
-                if (new_op == k) L_ring[k * RING + tail[k] + rank] = (unsigned char)slot;
-                tail[k] += (uint32_t)__popcll(mk_);
-            }
-        }
-
-        // ---- strip finished: resolve and store 16 pixels with one coalesced 64-B write ----
-        {
-            const RenderArgs& AS = per_strip_args();
-            if (AS.accum) {                      // progressive mode: add the exact sums, resolve later
-                if (lane < strip_pixels * 3) AS.accum[3ull * base_pix + lane] += L_acc[lane];
-            } else if (lane < strip_pixels) {
-                const uint32_t rgba = pack_rgba(resolve_channel(L_acc[lane * 3 + 0], AS.spp, AS.flags),
-                                                resolve_channel(L_acc[lane * 3 + 1], AS.spp, AS.flags),
-                                                resolve_channel(L_acc[lane * 3 + 2], AS.spp, AS.flags));
-                AS.out[base_pix + lane] = rgba;
-            }
-            work.flush(AS.counters, lane);
-        }
-    }
-}
+// The kernel's text lives in mirt_pool_kernel.inc and is compiled twice: the default build and the tile build.
+#define MIRT_POOL_KERNEL_NAME render_pt_pool_kernel
+#define MIRT_POOL_KERNEL_TILE false
+#include "mirt_pool_kernel.inc"
+#undef MIRT_POOL_KERNEL_NAME
+#undef MIRT_POOL_KERNEL_TILE
+#define MIRT_POOL_KERNEL_NAME render_pt_pool_tile_kernel
+#define MIRT_POOL_KERNEL_TILE true
+#include "mirt_pool_kernel.inc"
+#undef MIRT_POOL_KERNEL_NAME
+#undef MIRT_POOL_KERNEL_TILE
 
 #ifdef MIRT_ISA_PROBES
 // ------------------------------------------------------------------------------------------
@@ -1700,6 +1437,23 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false>, g, b, a, stream);
 }
 
+// the tile build (MIRT_FLAG_TEXEL_TILES): fewer slots, a texel window per wave
+template <uint32_t T, uint32_t SL, uint32_t MW>
+static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
+{
+    const dim3 g(grid_blocks), b(T);
+#ifdef MIRT_FAST_MATH
+    if (count) return hipErrorInvalidValue;
+#else
+    if (count) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, 1, true, true>, g, b, a, stream)
+                            : launch_with_lds(render_pt_pool_tile_kernel<T, SL, 1, true, false>, g, b, a, stream);
+#endif
+    if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false>, g, b, a, stream);
+}
+
 // grid build of the default pool geometry: LDS (scene + grid + pools) bounds it to a few blocks per CU, so the
 // register budget is not the limit
 static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
@@ -1731,7 +1485,8 @@ static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bo
 // resident in a CU's 160 KB of LDS.  Measured on config 3: 128 slots (5 waves/SIMD)
 // +2.5 % time; 64 slots -> 68 % lane use, 1.4x; 256 slots -> 8 waves per CU, 1.7x; 88 slots at 7
 // waves per SIMD (72 VGPRs, spills) +10 %.
-static const PoolConfig kPoolConfigs[] = { { 256, 112, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 }, { 256, 96, 0 } };
+// [kTilePoolConfig] is the tile build: the default geometry + a texel window per wave in the spare LDS of its 6 blocks per CU.
+static const PoolConfig kPoolConfigs[] = { { 256, 112, 0 }, { 256, 128, 0 }, { 256, 64, 0 }, { 256, 256, 0 }, { 256, 96, 0 }, { 256, kTilePoolSlots, 0 } };
 
 uint32_t pool_config_count() { return (uint32_t)(sizeof(kPoolConfigs) / sizeof(kPoolConfigs[0])); }
 
@@ -1747,6 +1502,8 @@ PoolConfig pool_config(uint32_t i, uint32_t nq)
 {
     PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
     c.lds_bytes = (nq <= 3 ? pool_bytes_per_wave<3>(c.slots) : pool_bytes_per_wave<5>(c.slots)) * (c.threads / 64);
+    if (i == kTilePoolConfig)
+        c.lds_bytes = (nq <= 3 ? WavePoolLayout<kTilePoolSlots, 3, false, true>::kBytes : WavePoolLayout<kTilePoolSlots, 5, false, true>::kBytes) * (c.threads / 64);
     return c;
 }
 
@@ -1773,6 +1530,7 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
     case 2:  return launch_pool_cfg<256, 64>(a, grid_blocks, count, hosek, nq, stream);
     case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, nq, stream);
     case 4:  return launch_pool_cfg<256, 96, 7>(a, grid_blocks, count, hosek, nq, stream);     // 7 waves per SIMD: <= 72 VGPRs
+    case kTilePoolConfig: return launch_pool_tile<256, kTilePoolSlots, 6>(a, grid_blocks, count, hosek, nq, stream);
     default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, nq, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
 }
@@ -1790,9 +1548,14 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
         case 2: slots = 64; minw = 1; break;
         case 3: slots = 256; minw = 1; break;
         case 4: slots = 96; minw = 7; break;
+        case kTilePoolConfig: slots = kTilePoolSlots; break;
         default: break;
         }
         if (count) { minw = 1; nq = 5; } else nq = (nq <= 3) ? 3 : 5;
+        if (cfg == kTilePoolConfig) {
+            snprintf(out, out_len, "render_pt_pool_tile_kernel<%u,%u,%u,%s,%s,%u,false>", threads, slots, minw, tf[count], tf[hosek], nq);
+            return;
+        }
     }
     snprintf(out, out_len, "render_pt_pool_kernel<%u,%u,%u,%s,%s,%u,%s>", threads, slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
 }
