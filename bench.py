@@ -234,6 +234,40 @@ def fast_math_line(m, torch, ctx, base, exact_frame, total_samples: int, flops: 
             "note": "opt-in build: hardware rcp/rsq/sqrt/sin/cos/exp/log + contraction; no parity claim; not the reported value"}
 
 
+def texel_tiles_line(m, torch, ctx, base, default_frame, total_samples: int, launches: int = 5) -> dict:
+    """The OPT-IN LDS texel-tile build (MIRT_FLAG_TEXEL_TILES; BASELINE configs[3] "LDS texel tiles") on the same workload,
+    outside the timed region and never part of `value`: kernel time from HIP events, that its frame equals the default
+    build's, and the tile hit rates from one counting launch at a tenth of the samples."""
+    import copy
+    p = copy.copy(base)
+    p.flags |= m.MIRT_FLAG_TEXEL_TILES
+    out = torch.empty_like(default_frame)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.render_device(p, out.data_ptr(), out.numel(), stream)            # warm-up
+    torch.cuda.synchronize()
+    ctx.stats()
+    for _ in range(launches):
+        ctx.render_device(p, out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    ms = st["kernel_ms_total"] / max(1, st["launches"])
+    kernel = ctx.last_kernel()
+    pc = copy.copy(p)
+    pc.flags |= m.MIRT_FLAG_COUNT_WORK
+    pc.spp = max(48, p.spp // 10)
+    scratch = torch.empty_like(default_frame)
+    ctx.render_device(pc, scratch.data_ptr(), scratch.numel(), stream)
+    torch.cuda.synchronize()
+    cs = ctx.stats()
+    f, t = cs["texel_fetches"], cs["texel_tile_hits"]
+    return {"kernel": kernel, "kernel_ms_avg": round(ms, 4), "value_from_kernel_time": round(total_samples / ms / 1e3, 2), "unit": "Msamples/s",
+            "frame_identical_to_default_build": bool(torch.equal(out, default_frame)),
+            "image_texel_fetches_per_sample": round((f[0] + f[1]) / max(1, cs["samples"]), 4),
+            "tile_hit_rate_pct": {"camera_ray_hits": round(100.0 * t[0] / max(1, f[0]), 2), "later_bounces": round(100.0 * t[1] / max(1, f[1]), 2),
+                                  "all": round(100.0 * (t[0] + t[1]) / max(1, f[0] + f[1]), 2)},
+            "note": "opt-in build: a 16x2-texel LDS window per wave and strip; same texel values, so the same image; not the reported value"}
+
+
 def verify_rows(m, sd, cfg: dict, frame_host, budget_seconds: float = 40.0) -> list:
     """Rows of the TIMED frame against oracle rows at the full sample count; the checker runs after the clock stopped."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -522,6 +556,8 @@ def main(argv=None) -> int:
         }
         if world == 1 and cfg["mode"] == "pt":
             result["fast_math"] = fast_math_line(m, torch, ctx, base, frame.frame, total_samples, flops)
+            if args.config == "4":
+                result["texel_tiles"] = texel_tiles_line(m, torch, ctx, base, frame.frame, total_samples)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, sd, cfg)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)

@@ -46,3 +46,11 @@ def test_other_configs_emit_the_same_shape(config, kernel):
     assert "cpu_baseline" not in d and "verified_rows" not in d
     if config == "5":
         assert d["roofline"]["grid_walk_lane_utilization"] > 0.5
+
+
+def test_config4_line_reports_the_texel_tile_build():
+    d = _bench("--config", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert CONTRACT <= set(d) and d["roofline"]["kernel"].startswith("render_pt_pool_kernel<256,")
+    t = d["texel_tiles"]
+    assert t["kernel"].startswith("render_pt_pool_tile_kernel<256,") and t["frame_identical_to_default_build"] is True
+    assert t["tile_hit_rate_pct"]["camera_ray_hits"] > 50.0 > t["tile_hit_rate_pct"]["later_bounces"]
