@@ -233,7 +233,8 @@ typedef enum MirtStatus {
     MIRT_ERR_FRAME_SPP            = -19, /* frame_spp does not divide spp / sample_begin */
     MIRT_ERR_NO_DEVICE            = -20,
     MIRT_ERR_HIP                  = -21,
-    MIRT_ERR_ALLOC                = -22
+    MIRT_ERR_ALLOC                = -22,
+    MIRT_ERR_IMAGE_DECODE         = -23  /* mirt_jpeg_*: not a JPEG this decoder handles (TextureError::ImageLoadError, texture.rs:193-199) */
 } MirtStatus;
 
 typedef struct MirtContext MirtContext; /* opaque: one per device; owns all device memory */
@@ -345,6 +346,16 @@ int mirt_render(const MirtScene* scene, const MirtParams* params, int device,
 /* RGBA8 -> RGB8 view for `Layer::imgbuf()` (layer.rs:182-186; `ImageBuffer<Rgb<u8>>`). Host-side
  * repack of n_pixels pixels. */
 int mirt_rgba8_to_rgb8(const uint8_t* rgba, size_t n_pixels, uint8_t* rgb);
+
+/* `Texture::new_from_image` (texture.rs:21-46): JPEG file bytes -> RGB8 -> `inv_255 * (p as f32)` texels, host side, so
+ * that a host gets from the reference's `assets/earthmap.jpeg` / `assets/moon.jpeg` to MirtScene.texels with this
+ * library alone.  Baseline and progressive Huffman JPEG, 8 bit, grey or 3 components, 4:4:4 / 4:2:2 / 4:2:0 (csrc/mirt_jpeg.cpp);
+ * other files fail with MIRT_ERR_IMAGE_DECODE and a message in mirt_jpeg_last_error().  The decode is bit-identical to
+ * libjpeg-turbo's (tests/test_jpeg.py); against the `image` crate it is decoder-unpinned.  No device involved. */
+int mirt_jpeg_info(const uint8_t* data, size_t len, uint32_t* width, uint32_t* height);
+int mirt_jpeg_decode_rgb8(const uint8_t* data, size_t len, uint8_t* rgb, size_t rgb_len);   /* rgb_len >= width * height * 3 */
+int mirt_rgb8_to_texels(const uint8_t* rgb, size_t n_pixels, float* texels);               /* texels: n_pixels x [f32;3] */
+const char* mirt_jpeg_last_error(void);
 
 /* Reassemble a full image from the `n_parts` compact buffers produced with the tile
  * interleave (root side of the multi-GPU gather).  `parts` holds n_parts buffers

@@ -179,5 +179,10 @@ extern "C" {
     pub fn mirt_ctx_selftest_math(ctx: *mut MirtContext, out_mismatches: *mut u64) -> c_int;
     pub fn mirt_render(scene: *const MirtScene, params: *const MirtParams, device: c_int, out_rgba8: *mut u8, out_len: usize) -> c_int;
     pub fn mirt_rgba8_to_rgb8(rgba: *const u8, n_pixels: usize, rgb: *mut u8) -> c_int;
+    // `Texture::new_from_image` (texture.rs:21-46) without the `image` crate: JPEG bytes -> RGB8 -> [f32;3] texels
+    pub fn mirt_jpeg_info(data: *const u8, len: usize, width: *mut u32, height: *mut u32) -> c_int;
+    pub fn mirt_jpeg_decode_rgb8(data: *const u8, len: usize, rgb: *mut u8, rgb_len: usize) -> c_int;
+    pub fn mirt_rgb8_to_texels(rgb: *const u8, n_pixels: usize, texels: *mut f32) -> c_int;
+    pub fn mirt_jpeg_last_error() -> *const c_char;
     pub fn mirt_ctx_deinterleave_device(ctx: *mut MirtContext, params: *const MirtParams, d_parts: *const c_void, part_stride: usize, d_out_rgba8: *mut c_void, out_len: usize, hip_stream: *mut c_void) -> c_int;
 }

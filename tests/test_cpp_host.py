@@ -41,7 +41,22 @@ def test_cpp_layer_tables_and_validation(ppms):
     assert lines[2] == "validate: MIRT_ERR_MAX_SAMPLES_MULTIPLE"
 
 
+@pytest.mark.skipif(not Path("/root/reference/assets/moon.jpeg").exists(), reason="the reference tree is not present on this machine")
+def test_cpp_layer_scene_from_the_reference_jpegs(ppms):
+    """`Layer::scene` as the reference writes it (layer.rs:97,108): straight from assets/*.jpeg through the library's JPEG
+    decoder -- the same texel table, bit for bit, as from the committed decodes."""
+    a = subprocess.run([str(DEMO), "--host-only", ppms["moon"], ppms["earthmap"]], capture_output=True, text=True, timeout=120)
+    b = subprocess.run([str(DEMO), "--host-only", "/root/reference/assets/moon.jpeg", "/root/reference/assets/earthmap.jpeg"],
+                       capture_output=True, text=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert a.stdout == b.stdout and "texels fnv" in a.stdout
+
+
 def test_cpp_texture_errors(ppms, tmp_path):
+    bad = tmp_path / "not_a.jpeg"
+    bad.write_bytes(b"\xff\xd8\xff\xc3" + bytes(40))            # SOI + a lossless frame header
+    r = subprocess.run([str(DEMO), "--host-only", str(bad), ppms["earthmap"]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "TextureError::ImageLoadError" in r.stderr
     r = subprocess.run([str(DEMO), "--host-only", str(tmp_path / "missing.ppm"), ppms["earthmap"]], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "TextureError::IoError" in r.stderr
 

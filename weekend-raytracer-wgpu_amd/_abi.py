@@ -43,6 +43,7 @@ STATUS = {
     -20: "MIRT_ERR_NO_DEVICE",
     -21: "MIRT_ERR_HIP",
     -22: "MIRT_ERR_ALLOC",
+    -23: "MIRT_ERR_IMAGE_DECODE",
 }
 for _code, _name in STATUS.items():
     globals()[_name] = _code
@@ -152,6 +153,10 @@ SYMBOLS = {
     "mirt_ctx_selftest_math": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "mirt_render": (C.c_int, [_P(MirtScene), _P(MirtParams), C.c_int, C.c_void_p, C.c_size_t]),
     "mirt_rgba8_to_rgb8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mirt_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_uint32), _P(C.c_uint32)]),
+    "mirt_jpeg_decode_rgb8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "mirt_rgb8_to_texels": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mirt_jpeg_last_error": (C.c_char_p, []),
     "mirt_ctx_deinterleave_device": (C.c_int, [C.c_void_p, _P(MirtParams), C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_size_t, C.c_void_p]),
 }

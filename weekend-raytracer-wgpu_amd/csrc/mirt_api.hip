@@ -318,6 +318,7 @@ const char* mirt_status_string(int status)
     case MIRT_ERR_NO_DEVICE: return "MIRT_ERR_NO_DEVICE";
     case MIRT_ERR_HIP: return "MIRT_ERR_HIP";
     case MIRT_ERR_ALLOC: return "MIRT_ERR_ALLOC";
+    case MIRT_ERR_IMAGE_DECODE: return "MIRT_ERR_IMAGE_DECODE";
     default: return "MIRT_ERR_UNKNOWN";
     }
 }

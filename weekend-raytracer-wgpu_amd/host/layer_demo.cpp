@@ -66,6 +66,11 @@ int main(int argc, char** argv)
         bad.sampling.max_samples_per_pixel = 7; bad.sampling.num_samples_per_pixel = 2;
         try { bad.validate(); std::printf("validate: no error?!\n"); return 1; }
         catch (const MirtError& e) { std::printf("validate: %s\n", mirt_status_string(e.status)); }
+        {   // a checksum of the texel table's bits (the JPEG and the PPM route must build the same table)
+            uint64_t sum = 0;
+            for (float t : layer.global_texture_data()) { uint32_t u; std::memcpy(&u, &t, 4); sum = sum * 1099511628211ull + u; }
+            std::printf("texels fnv %016llx\n", (unsigned long long)sum);
+        }
         if (host_only) return 0;
         layer.set_data(rp);
         const auto& rgba = layer.register_texture();

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
+#include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -117,9 +118,21 @@ public:
         for (size_t i = 0; i < t.data_.size(); ++i) t.data_[i] = inv_255 * (float)rgb[i];
         return t;
     }
-    static Texture new_from_image(const std::string& path) {       // texture.rs:21-46 (TextureError::IoError on failure)
+    // texture.rs:21-46.  JPEG files (what the reference loads: assets/moon.jpeg, assets/earthmap.jpeg) go through the
+    // library's own decoder (mirt_jpeg_decode_rgb8); binary PPM is accepted beside it for already-decoded texels.
+    static Texture new_from_image(const std::string& path) {       // TextureError::FileIoError / ImageLoadError on failure
         std::ifstream f(path, std::ios::binary);
         if (!f) throw std::runtime_error("TextureError::IoError: cannot open " + path);
+        if (f.peek() == 0xff) {
+            std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            uint32_t jw = 0, jh = 0;
+            if (mirt_jpeg_info(bytes.data(), bytes.size(), &jw, &jh) != MIRT_OK)
+                throw std::runtime_error(std::string("TextureError::ImageLoadError: ") + mirt_jpeg_last_error() + ": " + path);
+            std::vector<uint8_t> rgb((size_t)jw * jh * 3);
+            if (mirt_jpeg_decode_rgb8(bytes.data(), bytes.size(), rgb.data(), rgb.size()) != MIRT_OK)
+                throw std::runtime_error(std::string("TextureError::ImageLoadError: ") + mirt_jpeg_last_error() + ": " + path);
+            return new_from_rgb8(rgb.data(), jw, jh);
+        }
         std::string magic; uint32_t w = 0, h = 0, maxv = 0;
         f >> magic >> w >> h >> maxv;
         if (magic != "P6" || maxv != 255 || w == 0 || h == 0) throw std::runtime_error("TextureError::ImageLoadError: not a binary PPM: " + path);

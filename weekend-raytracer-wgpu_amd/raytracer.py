@@ -232,18 +232,27 @@ class Texture:
 
     @staticmethod
     def new_from_image(path: str) -> "Texture":       # texture.rs:21-46
-        """Decode an image file.  `.npz` (key `rgb8`) and `.npy` hold already-decoded RGB8 texels;
-        anything else is decoded with Pillow (DECODER-UNPINNED against the `image` crate's JPEG
-        decoder: +-1 LSB per texel is possible; nothing in the reference pins either)."""
+        """Decode an image file.  `.npz` (key `rgb8`) and `.npy` hold already-decoded RGB8 texels; anything else is read
+        as a JPEG (the reference passes `ImageFormat::Jpeg`, texture.rs:27-28) and decoded by the library's own decoder
+        (csrc/mirt_jpeg.cpp: bit-identical to libjpeg-turbo; DECODER-UNPINNED against the `image` crate's jpeg-decoder,
+        +-1 LSB in some texels is possible and nothing in the reference pins either)."""
         p = Path(path)
         if not p.exists():
-            raise FileNotFoundError(path)             # TextureError::IoError
+            raise FileNotFoundError(path)             # TextureError::FileIoError
         if p.suffix == ".npz":
             return Texture.new_from_rgb8(np.load(p)["rgb8"])
         if p.suffix == ".npy":
             return Texture.new_from_rgb8(np.load(p))
-        from PIL import Image
-        return Texture.new_from_rgb8(np.asarray(Image.open(p).convert("RGB"), dtype=np.uint8))
+        return Texture.new_from_jpeg_bytes(p.read_bytes())
+
+    @staticmethod
+    def new_from_jpeg_bytes(data: bytes) -> "Texture":
+        """JPEG bytes -> RGB8 (mirt_jpeg_decode_rgb8) -> `inv_255 * (p as f32)` texels (mirt_rgb8_to_texels)."""
+        rgb = decode_jpeg(data)
+        h, w, _ = rgb.shape
+        texels = np.empty((h * w, 3), dtype=np.float32)
+        check(lib().mirt_rgb8_to_texels(rgb.ctypes.data_as(C.c_void_p), h * w, texels.ctypes.data_as(C.c_void_p)))
+        return Texture((w, h), texels.reshape(h, w, 3))
 
     @staticmethod
     def new_from_color(color) -> "Texture":           # texture.rs:48-54
@@ -344,6 +353,26 @@ _ASSET_FIXTURES = {
     "assets/moon.jpeg": "moon_1024x512_rgb8.npz",
     "assets/earthmap.jpeg": "earthmap_1024x512_rgb8.npz",
 }
+
+
+def _jpeg_check(rc: int) -> None:
+    if rc != 0:
+        raise MirtError(rc, (lib().mirt_jpeg_last_error() or b"").decode())
+
+
+def jpeg_info(data: bytes) -> Tuple[int, int]:
+    """(width, height) of a JPEG file's frame header."""
+    w, h = C.c_uint32(), C.c_uint32()
+    _jpeg_check(lib().mirt_jpeg_info(data, len(data), C.byref(w), C.byref(h)))
+    return int(w.value), int(h.value)
+
+
+def decode_jpeg(data: bytes) -> np.ndarray:
+    """JPEG file bytes -> uint8 [h, w, 3] with the library's decoder (no device involved)."""
+    w, h = jpeg_info(data)
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    _jpeg_check(lib().mirt_jpeg_decode_rgb8(data, len(data), out.ctypes.data_as(C.c_void_p), out.nbytes))
+    return out
 
 
 def asset_path(name: str) -> str:
@@ -519,4 +548,4 @@ class Raytracer:
 __all__ = ["Angle", "Camera", "GpuCamera", "SamplingParams", "SkyParams", "RenderParams",
            "RenderParamsValidationError", "FlyCameraController", "Sphere", "Texture", "Material",
            "TextureDescriptor", "GpuMaterial", "Scene", "Layer", "Raytracer", "flatten_materials",
-           "asset_path", "MirtError"]
+           "asset_path", "MirtError", "decode_jpeg", "jpeg_info"]
