@@ -248,6 +248,7 @@ struct MirtContext {
     uint32_t n_spheres = 0, n_mats = 0;
     uint64_t n_texels = 0;
     bool     have_sky = false;
+    float    sph3[12] = {};               // {centre, r^2} of the spheres of a three-sphere scene (RenderArgs.sph3)
     bool     has_image_texture = false;   // a material refers to a texture larger than 1x1
     uint32_t n_shading_routines = 0;      // distinct scatter routines the spheres' materials select
     uint32_t queue_routine[5] = {0, 1, 2, 3, 4};   // dense numbering of the routines present (pool kernel queues)
@@ -575,6 +576,8 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     c->n_spheres = s->n_spheres;
     c->n_mats = s->n_materials;
     c->n_texels = s->n_texels;
+    for (uint32_t i = 0; i < 3; ++i)
+        for (int k = 0; k < 4; ++k) c->sph3[4 * i + k] = (s->n_spheres == 3) ? (&prep[i].cx)[k] : 0.0f;
     c->has_image_texture = false;                // ... on a material some sphere uses
     for (uint32_t i = 0; i < s->n_spheres; ++i)
         if (s->spheres[i].material_idx < s->n_materials && mat_has_image[s->spheres[i].material_idx]) c->has_image_texture = true;
@@ -699,6 +702,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     for (int q = 0; q < 5; ++q) a.queue_routine[q] = c->queue_routine[q];
+    for (int k = 0; k < 12; ++k) a.sph3[k] = c->sph3[k];
     a.n_units = (uint32_t)((npix + mirt::kStripPixels - 1) / mirt::kStripPixels);
     for (uint32_t l = 0; l <= mirt::kStripLevels; ++l) { a.lvl_unit[l] = a.n_units; a.lvl_pix[l] = (uint32_t)npix; }
     a.lvl_unit[0] = 0;

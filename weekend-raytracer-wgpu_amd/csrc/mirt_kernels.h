@@ -129,6 +129,7 @@ struct RenderArgs {
     uint32_t lvl_pix[6];
     uint32_t queue_routine[5];             // pool kernel: scatter queue q runs routine queue_routine[q] = min(GpuMaterial.id, 4)
     uint32_t lds_bytes;
+    float    sph3[12];                     // scenes of exactly three spheres: their {centre, r^2} records as kernel arguments (scalar loads)
 };
 
 struct DeinterleaveArgs {

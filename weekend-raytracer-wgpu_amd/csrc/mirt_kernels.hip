@@ -467,6 +467,8 @@ struct CamRegs {
 MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
 {
     CamRegs c;
+    // (reading the camera with scalar loads from the kernel arguments instead -- it is RenderArgs' first member -- was measured:
+    //  +5.4 % on config 3, the scan's three sphere records are the only data for which that pays)
     c.eye = mk(S.cam[0], S.cam[1], S.cam[2]);
     c.hor = mk(S.cam[4], S.cam[5], S.cam[6]);
     c.ver = mk(S.cam[8], S.cam[9], S.cam[10]);
@@ -544,7 +546,12 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
     // loop bookkeeping.  Measured on config 3 (tools/ab_libs.py, interleaved rounds): -1.5 %; the same treatment for
     // lists of 1, 2 and 4 spheres behind one switch cost the three-sphere case 1.7 % and was dropped.
     if (n_spheres == 3u) {
-        const float4 s0 = sph[0], s1 = sph[2], s2 = sph[4];
+        // the three records come from the kernel arguments (RenderArgs.sph3, filled by the host for such scenes): scalar
+        // loads into SGPRs that live only for this scan -- no LDS round trip, no VGPRs for the records (-0.5 %)
+        const RenderArgs& AK = per_strip_args();
+        const float4 s0 = make_float4(AK.sph3[0], AK.sph3[1], AK.sph3[2], AK.sph3[3]);
+        const float4 s1 = make_float4(AK.sph3[4], AK.sph3[5], AK.sph3[6], AK.sph3[7]);
+        const float4 s2 = make_float4(AK.sph3[8], AK.sph3[9], AK.sph3[10], AK.sph3[11]);
         hit_sphere<COUNT>(s0, 0, ro, rd, a, inv_a, alive, closest, best, work);
         hit_sphere<COUNT>(s1, 1, ro, rd, a, inv_a, alive, closest, best, work);
         hit_sphere<COUNT>(s2, 2, ro, rd, a, inv_a, alive, closest, best, work);
