@@ -394,6 +394,8 @@ def main(argv=None) -> int:
         print("bench.py: no GPU visible; the render path has no CPU fallback (use --dry-run to rehearse the rank plumbing)", file=sys.stderr)
         return 3
     if not dry:
+        # one rank per GPU; with fewer GPUs than ranks (a rehearsal on a one-GPU box) the ranks share devices
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
