@@ -366,6 +366,8 @@ def parse_args(argv):
     ap.add_argument("--config", choices=sorted(CONFIGS), default="3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline, verified_rows)")
     ap.add_argument("--tile-rows", type=int, default=4)
+    ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel (e.g. --config 5 --gpus 8 --spp 4000 = "
+                                                        "BASELINE configs[4] in full); the workload string says so")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank path on CPU (gloo, pattern renderer); measures nothing")
     return ap.parse_args(argv)
 
@@ -407,6 +409,9 @@ def main(argv=None) -> int:
     import weekend_raytracer_wgpu_amd as m
 
     cfg = dict(CONFIGS[args.config])
+    if args.spp > 0 and args.spp != cfg["spp"]:
+        cfg["workload"] += f" [spp overridden: {args.spp} instead of {cfg['spp']}]"
+        cfg["spp"] = args.spp
     if dry:                                               # small frame: the pattern renderer is numpy
         cfg.update(width=192, height=108, spp=1)
     w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
