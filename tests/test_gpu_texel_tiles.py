@@ -88,3 +88,27 @@ def _retexture(sd, texels, tw, th):
         elif d.offset > off and d.width * d.height >= 1:
             d.offset += texels.shape[0] - n
     return m.SceneData(sd.camera, sd.spheres, mats, table, sd.sky)
+
+
+def test_tile_build_in_progressive_accumulation_and_parts(gpu_ctx, oracle):
+    """The tile build behind the accumulation API (exact sums) and behind the multi-GPU row partition."""
+    w, h = 320, 180
+    sd = scene_data("earth", w, h)
+    gpu_ctx.set_scene(sd)
+    sums = {}
+    for fl in (0, TILES):
+        base = _pt(w, h, 64, flags=fl)
+        gpu_ctx.accum_reset(base)
+        for k in range(2):
+            gpu_ctx.accum_add(_pt(w, h, 64, flags=fl, sample_begin=64 * k))
+        assert gpu_ctx.last_kernel().startswith("render_pt_pool_tile_kernel<" if fl else "render_pt_pool_kernel<")
+        sums[fl] = gpu_ctx.accum_read(base)
+    assert np.array_equal(sums[0], sums[TILES])
+    assert np.array_equal(sums[0], oracle.render_pt_sums(sd, _pt(w, h, 128)))
+    base = _pt(w, h, 64, flags=TILES)
+    full = gpu_ctx.render(base)
+    parts = np.zeros((4, m.multi_gpu.max_part_rows(base, 4, 4), w, 4), np.uint8)
+    for r in range(4):
+        img = gpu_ctx.render(m.multi_gpu.part_params(base, r, 4, 4))
+        parts[r, :img.shape[0]] = img
+    assert_images_equal(m.multi_gpu.assemble_host(parts, base, 4, 4), full, "4-way tiles with the texel-tile build")
