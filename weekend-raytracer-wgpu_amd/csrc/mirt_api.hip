@@ -658,12 +658,15 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const uint32_t pool_nq = kx::pool_scatter_queues(c->n_shading_routines, count);
     const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
-    // pools still leave >= 16 waves per CU resident beside the scene tables.  Since fast-forwarding (round 2) that
-    // holds for single-routine scenes too -- paths still end at different depths, which the pool re-compacts --
-    // (single metal sphere, 1080p x 100 spp: 1.81 ms against the strip kernel's 2.27; 3 spheres 1.5x, 5 spheres 1.6x).
+    // pools still leave >= 16 waves per CU resident beside the scene tables; the sample counts from which it does are
+    // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 40 for scenes
+    // with several shading routines, 160 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
+    // beat: single metal sphere, 1080p x 100 spp, 1.51 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
+    // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
     const uint32_t pool_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_block ? lds_pool_block : 1)) * (pc.threads / 64u);
-    bool pool = pt && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 1 && pool_waves_per_cu >= 16;
+    const uint32_t pool_min_spp = c->n_shading_routines <= 1 ? mirt::kPoolMinSppOneRoutine : mirt::kPoolMinSpp;
+    bool pool = pt && p->spp >= pool_min_spp && c->n_shading_routines >= 1 && pool_waves_per_cu >= 16;
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
     // the reference's per-frame RNG stream makes a pixel's samples sequentially dependent: lane-per-pixel strip kernel only
@@ -685,7 +688,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && tune.pool_config < 0 && p->num_bounces <= 255u &&
                      !(p->flags & MIRT_FLAG_KERNEL_STRIP) && !frame_stream &&
                      ((p->flags & MIRT_FLAG_KERNEL_POOL) ||
-                      (!pool && p->spp >= mirt::kPoolMinSpp && c->n_shading_routines >= 1 && pool_grid_waves_per_cu >= 16));
+                      (!pool && p->spp >= mirt::kPoolMinSppGrid && c->n_shading_routines >= 1 && pool_grid_waves_per_cu >= 16));
     if (tune.pool_grid == 0) pool_grid = false;
     if (pool_grid) pool = true;
     const mirt::PoolConfig pcu = pool_grid ? pcg : pc;                 // the geometry of the pool kernel that will run
@@ -752,7 +755,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
 
     // few samples per pixel (the reference's interactive loop adds 2 per frame): lane = pixel instead of lane = sample
-    bool by_pixel = pt && !pool && !count && p->spp < mirt::kByPixelMaxSpp;
+    bool by_pixel = pt && !pool && !count && (p->spp < mirt::kByPixelMaxSpp || c->n_shading_routines <= 1);
     if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
     if (frame_stream) by_pixel = true;                    // also for counting launches (flat scan) and any spp
     a.static_units = 0;

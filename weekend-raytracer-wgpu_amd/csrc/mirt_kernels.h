@@ -78,14 +78,24 @@ constexpr uint32_t kDefaultPoolConfig = 0;
 #define MIRT_TILE_SLOTS 112
 #endif
 constexpr uint32_t kTilePoolConfig = 5, kTilePoolSlots = MIRT_TILE_SLOTS;
-constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel
+constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many samples per pixel a wave takes 64 pixels, lane = pixel (scenes with
+                                          // one shading routine: at any sample count -- nothing diverges, 1.51 ms against 2.27 on config 2)
 // pool kernel, grid build (many-sphere scenes): ONE 1024-thread block per CU, so that the grid blob (~20 KB for RTIOW)
 // is staged once for all 16 waves and the rest of the 160 KB goes to the path pools.  Measured on RTIOW 1080p x 128 spp:
 // 512 threads x 112 slots, two blocks 17.3 ms; x 128 slots 16.6; 1024 x 144 15.9; 1024 x 152 15.7; one 512-thread
 // block per CU (8 waves) with 160-256 slots 26.3 -- the pools want to be as large as 16 resident waves allow.
 constexpr uint32_t kGridPoolThreads = 1024;
 constexpr uint32_t kGridPoolSlotChoices[3] = { 152, 128, 96 };   // the largest geometry whose block fits LDS is taken
-constexpr uint32_t kPoolMinSpp    = 48;   // below this a strip's work list cannot keep the pool full: strip kernel
+// Samples per pixel from which the pooled kernel is the default (below: the strip kernel, lane = pixel).  A 16-pixel strip
+// of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
+// measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
+//   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40
+//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): strip 1.51 / 1.97 / 2.44 / 3.00 ms at
+//   100 / 128 / 160 / 192 spp, pool 1.82 / 2.15 / 2.40 / 2.68                                                          -> 160
+//   many-sphere scenes (grid build, RTIOW): strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66   -> 16
+constexpr uint32_t kPoolMinSpp           = 40;
+constexpr uint32_t kPoolMinSppOneRoutine = 160;
+constexpr uint32_t kPoolMinSppGrid       = 16;
 
 enum CounterSlot : uint32_t {
     kCntRays = 0, kCntTests, kCntRoots, kCntHits,
