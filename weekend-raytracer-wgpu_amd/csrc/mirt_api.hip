@@ -755,7 +755,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
 
     // few samples per pixel (the reference's interactive loop adds 2 per frame): lane = pixel instead of lane = sample
-    bool by_pixel = pt && !pool && !count && (p->spp < mirt::kByPixelMaxSpp || c->n_shading_routines <= 1);
+    // (single-routine scenes: lane = pixel at any sample count, but only for frames that give every CU a few 64-pixel units;
+    //  a tiny frame with many samples per pixel needs the lanes of a wave on the samples)
+    bool by_pixel = pt && !pool && !count && (p->spp < mirt::kByPixelMaxSpp || (c->n_shading_routines <= 1 && npix >= 64ull * 4u * c->cu_count));
     if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
     if (frame_stream) by_pixel = true;                    // also for counting launches (flat scan) and any spp
     a.static_units = 0;
