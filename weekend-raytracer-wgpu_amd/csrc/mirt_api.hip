@@ -780,7 +780,14 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     } else {
         const uint32_t waves_per_block = mirt::kBlockThreads / 64;
         blocks = (a.n_units + waves_per_block - 1) / waves_per_block;
-        const uint32_t resident = (uint32_t)c->cu_count * 8u;     // 2048 threads per CU / 256
+        // a persistent grid of exactly the blocks that are resident at once: registers and LDS decide (4-8 per CU for these
+        // kernels).  A block beyond that would hold its first unit until the dispenser has run dry and run it alone at the end.
+        const bool fast_strip = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
+        uint32_t per_cu = !pt ? kx::parity_blocks_per_cu(count, a.lds_bytes)
+                        : fast_strip ? kf::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes)
+                                     : kx::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes);
+        if (per_cu > 8u) per_cu = 8u;                                 // 2048 threads per CU / 256
+        const uint32_t resident = (uint32_t)c->cu_count * per_cu;
         if (blocks > resident) blocks = resident;
     }
     if (blocks == 0) blocks = 1;

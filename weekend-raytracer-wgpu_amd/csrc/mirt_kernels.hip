@@ -18,6 +18,7 @@
 //
 // Compiled with -ffp-contract=off: every fused multiply-add in this file is an explicit fma_().
 #include <cstdio>
+#include <mutex>
 
 #include "mirt_kernels.h"
 #include "mirt_device_math.h"
@@ -1407,31 +1408,69 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, 
 
 #endif
 
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
+using StripKernel = void (*)(RenderArgs);
+
+// the build of the strip kernel a launch runs (nullptr: no such build -- counting launches of the fast-math library)
+static StripKernel strip_kernel(bool count, bool hosek, bool use_grid, bool by_pixel)
 {
-    const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
-    const dim3 g(grid_blocks), b(kBlockThreads);
 #ifdef MIRT_FAST_MATH
-    if (count) return hipErrorInvalidValue;              // the counting builds exist in the exact build only
+    if (count) return nullptr;                           // the counting builds exist in the exact build only
 #else
-    if (count && use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, true>, g, b, a, stream)
-                                        : launch_with_lds(render_pt_strip_kernel<true, false, true>, g, b, a, stream);
-    if (count && by_pixel) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false, true>, g, b, a, stream)
-                                        : launch_with_lds(render_pt_strip_kernel<true, false, false, true>, g, b, a, stream);
-    if (count) return hosek ? launch_with_lds(render_pt_strip_kernel<true, true, false>, g, b, a, stream)
-                            : launch_with_lds(render_pt_strip_kernel<true, false, false>, g, b, a, stream);
+    if (count && use_grid) return hosek ? render_pt_strip_kernel<true, true, true> : render_pt_strip_kernel<true, false, true>;
+    if (count && by_pixel) return hosek ? render_pt_strip_kernel<true, true, false, true> : render_pt_strip_kernel<true, false, false, true>;
+    if (count) return hosek ? render_pt_strip_kernel<true, true, false> : render_pt_strip_kernel<true, false, false>;
 #endif
     if (by_pixel) {
-        if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true, true>, g, b, a, stream)
-                                   : launch_with_lds(render_pt_strip_kernel<false, false, true, true>, g, b, a, stream);
-        return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, false, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_strip_kernel<false, false, false, true>, g, b, a, stream);
+        if (use_grid) return hosek ? render_pt_strip_kernel<false, true, true, true> : render_pt_strip_kernel<false, false, true, true>;
+        return hosek ? render_pt_strip_kernel<false, true, false, true> : render_pt_strip_kernel<false, false, false, true>;
     }
-    if (use_grid) return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, true>, g, b, a, stream)
-                               : launch_with_lds(render_pt_strip_kernel<false, false, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_strip_kernel<false, true, false>, g, b, a, stream)
-                 : launch_with_lds(render_pt_strip_kernel<false, false, false>, g, b, a, stream);
+    if (use_grid) return hosek ? render_pt_strip_kernel<false, true, true> : render_pt_strip_kernel<false, false, true>;
+    return hosek ? render_pt_strip_kernel<false, true, false> : render_pt_strip_kernel<false, false, false>;
 }
+
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
+{
+    const StripKernel k = strip_kernel(count, (a.flags & MIRT_FLAG_SKY_HOSEK) != 0, use_grid, by_pixel);
+    if (!k) return hipErrorInvalidValue;
+    return launch_with_lds(k, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
+}
+
+// Blocks of a kernel that are resident per CU at once (registers and LDS decide: the strip kernels use 59-106 VGPRs).  The
+// host sizes the persistent grids with it: a block that is launched but not resident holds its first work unit until some
+// other block exits, i.e. until the dispenser has run dry, and then runs that unit alone at the end of the launch.
+static uint32_t blocks_per_cu(const void* kernel, uint32_t threads, uint32_t lds_bytes)
+{
+    // asked once per (kernel, LDS size): the interactive loop launches every frame
+    struct Entry { const void* kernel; uint32_t lds, blocks; };
+    static Entry cache[64];
+    static uint32_t used = 0;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    for (uint32_t i = 0; i < used; ++i)
+        if (cache[i].kernel == kernel && cache[i].lds == lds_bytes) return cache[i].blocks;
+    uint32_t blocks = 1u;
+    int n = 0;
+    if ((lds_bytes <= 48u * 1024u ||
+         hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess) &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)threads, lds_bytes) == hipSuccess && n >= 1)
+        blocks = (uint32_t)n;
+    if (used < 64u) cache[used++] = Entry{ kernel, lds_bytes, blocks };
+    return blocks;
+}
+
+uint32_t strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes)
+{
+    const StripKernel k = strip_kernel(count, hosek, use_grid, by_pixel);
+    return k ? blocks_per_cu(reinterpret_cast<const void*>(k), kBlockThreads, lds_bytes) : 1u;
+}
+
+#ifndef MIRT_FAST_MATH
+uint32_t parity_blocks_per_cu(bool count, uint32_t lds_bytes)
+{
+    return count ? blocks_per_cu(reinterpret_cast<const void*>(render_parity_kernel<true>), kBlockThreads, lds_bytes)
+                 : blocks_per_cu(reinterpret_cast<const void*>(render_parity_kernel<false>), kBlockThreads, lds_bytes);
+}
+#endif
 
 template <uint32_t T, uint32_t SL, uint32_t MW = 1>
 static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
