@@ -1095,8 +1095,11 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
 // BY_PIXEL = true : a wave owns 64 consecutive pixels, lane = pixel, and every lane walks its pixel's samples
 //                   in turn -- the launch shape of the reference's interactive loop, which adds 2 samples per
 //                   pixel and frame (mod.rs:606-611): all 64 lanes carry a path whatever spp is, no reduction.
+// The plain lane-per-pixel build is held to 64 VGPRs (8 waves per SIMD instead of 7 at 71): -11 % on the single-sphere
+// scene (config 2: 1.54 -> 1.37 ms), -1 % on 2-spp frames, +1 ... +3 % on divergent scenes at 16-32 spp; the Hosek build
+// would spill and keeps its registers.
 template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL = false>
-__global__ __launch_bounds__(kBlockThreads) void render_pt_strip_kernel(RenderArgs A)
+__global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOSEK) ? 8 : 1) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // many-sphere scenes (GRID build): the material table (one 48-byte read per hit) stays in global memory / L2
