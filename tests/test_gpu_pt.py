@@ -487,7 +487,7 @@ def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
 
 def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
     """mirt_kernels.h kPoolMinSpp*: several shading routines -> pool from 40 spp; one routine -> lane-per-pixel strip kernel below
-    160 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
+    184 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
     choice renders the same image as the forced alternatives (checked throughout this file); here: the names."""
     def kernel(scene, w, h, spp):
         gpu_ctx.set_scene(scene_data(scene, w, h))
@@ -496,7 +496,8 @@ def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
     assert kernel("three_spheres", 640, 360, 36) == "render_pt_strip_kernel<false,false,false,true>"
     assert kernel("three_spheres", 640, 360, 40).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 640, 360, 100) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 160).startswith("render_pt_pool_kernel<256,112,6,")
+    assert kernel("single_sphere", 640, 360, 176) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("single_sphere", 640, 360, 184).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 64, 36, 100) == "render_pt_strip_kernel<false,false,false,false>"      # tiny frame: lanes on samples
     assert kernel("rtiow_final", 640, 360, 12) == "render_pt_strip_kernel<false,false,true,true>"
     assert kernel("rtiow_final", 640, 360, 16).startswith("render_pt_pool_kernel<1024,")

@@ -660,8 +660,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
     // pools still leave >= 16 waves per CU resident beside the scene tables; the sample counts from which it does are
     // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 40 for scenes
-    // with several shading routines, 160 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
-    // beat: single metal sphere, 1080p x 100 spp, 1.51 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
+    // with several shading routines, 184 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
+    // beat: single metal sphere, 1080p x 100 spp, 1.38 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
     // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
     const uint32_t pool_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_block ? lds_pool_block : 1)) * (pc.threads / 64u);

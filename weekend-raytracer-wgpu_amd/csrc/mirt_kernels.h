@@ -90,11 +90,11 @@ constexpr uint32_t kGridPoolSlotChoices[3] = { 152, 128, 96 };   // the largest 
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
 //   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40
-//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): strip 1.51 / 1.97 / 2.44 / 3.00 ms at
-//   100 / 128 / 160 / 192 spp, pool 1.82 / 2.15 / 2.40 / 2.68                                                          -> 160
+//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): strip 1.38 / 2.44 / 2.67 / 2.86 ms at
+//   100 / 176 / 192 / 208 spp, pool 1.82 / 2.49 / 2.63 / 2.76                                                          -> 184
 //   many-sphere scenes (grid build, RTIOW): strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66   -> 16
 constexpr uint32_t kPoolMinSpp           = 40;
-constexpr uint32_t kPoolMinSppOneRoutine = 160;
+constexpr uint32_t kPoolMinSppOneRoutine = 184;
 constexpr uint32_t kPoolMinSppGrid       = 16;
 
 enum CounterSlot : uint32_t {
