@@ -1097,9 +1097,11 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
 //                   pixel and frame (mod.rs:606-611): all 64 lanes carry a path whatever spp is, no reduction.
 // The plain lane-per-pixel build is held to 64 VGPRs (8 waves per SIMD instead of 7 at 71): -11 % on the single-sphere
 // scene (config 2: 1.54 -> 1.37 ms), -1 % on 2-spp frames, +1 ... +3 % on divergent scenes at 16-32 spp; the Hosek build
-// would spill and keeps its registers.
+// would spill and keeps its registers.  The grid build of the same schedule (many-sphere scenes below 16 spp) runs 7 waves
+// per SIMD at 72 VGPRs instead of 5 at 90, a few spilled registers included: RTIOW 2 / 8 spp 0.66 -> 0.62 / 1.92 -> 1.74 ms
+// (6 waves -2 / -6 %, 8 waves -5 / -8 %).
 template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL = false>
-__global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOSEK) ? 8 : 1) void render_pt_strip_kernel(RenderArgs A)
+__global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOSEK) ? 8 : ((BY_PIXEL && !COUNT && GRID) ? 7 : 1)) void render_pt_strip_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // many-sphere scenes (GRID build): the material table (one 48-byte read per hit) stays in global memory / L2
