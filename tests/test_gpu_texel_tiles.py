@@ -23,7 +23,7 @@ def test_tile_build_runs_and_matches_default_and_oracle(gpu_ctx, oracle):
     ref = gpu_ctx.render(_pt(w, h, spp))
     assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<256,112,")
     got = gpu_ctx.render(_pt(w, h, spp, flags=TILES))
-    assert gpu_ctx.last_kernel().startswith("render_pt_pool_tile_kernel<256,112,6,false,false,3,false>"), gpu_ctx.last_kernel()
+    assert gpu_ctx.last_kernel().startswith("render_pt_pool_tile_kernel<256,112,6,false,false,2,false>"), gpu_ctx.last_kernel()
     assert_images_equal(got, ref, "tile build vs default build")
     rows = _pt(w, h, spp, row_begin=260, row_end=264)
     assert_images_equal(got[260:264], oracle.render(sd, rows), "tile build vs oracle")

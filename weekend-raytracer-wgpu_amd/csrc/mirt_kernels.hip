@@ -1477,7 +1477,10 @@ uint32_t parity_blocks_per_cu(bool count, uint32_t lds_bytes)
 }
 #endif
 
-template <uint32_t T, uint32_t SL, uint32_t MW = 1>
+// builds of the pool kernel by scatter queues: 3 and 5 for every geometry; 1 and 2 as well (FEW = true) for the default and the
+// tile geometry -- a scene with fewer shading routines than queues would carry empty queues through every pick and push
+// (two routines, config 4: -1.2 %)
+template <uint32_t T, uint32_t SL, uint32_t MW = 1, bool FEW = false>
 static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
 {
     const dim3 g(grid_blocks), b(T);
@@ -1487,6 +1490,12 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
     if (count) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_kernel<T, SL, 1, true, false>, g, b, a, stream);
 #endif
+    if constexpr (FEW) {
+        if (nq == 1) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 1>, g, b, a, stream)
+                                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 1>, g, b, a, stream);
+        if (nq == 2) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 2>, g, b, a, stream)
+                                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 2>, g, b, a, stream);
+    }
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true>, g, b, a, stream)
@@ -1504,6 +1513,10 @@ static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bo
     if (count) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, 1, true, true>, g, b, a, stream)
                             : launch_with_lds(render_pt_pool_tile_kernel<T, SL, 1, true, false>, g, b, a, stream);
 #endif
+    if (nq == 1) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 1>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 1>, g, b, a, stream);
+    if (nq == 2) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 2>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 2>, g, b, a, stream);
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true>, g, b, a, stream)
@@ -1553,13 +1566,27 @@ static uint32_t pool_bytes_per_wave(uint32_t slots)
          : (slots == 112) ? WavePoolLayout<112, NQ>::kBytes : (slots == 128) ? WavePoolLayout<128, NQ>::kBytes : WavePoolLayout<256, NQ>::kBytes;
 }
 
-// nq = scatter queues of the build that will run (pool_scatter_queues): 3 or 5
+// the build that runs for a geometry: 1 / 2 queues exist for the default and the tile geometry only
+static uint32_t built_queues(uint32_t cfg, uint32_t nq)
+{
+    const bool few = cfg == kDefaultPoolConfig || cfg == kTilePoolConfig;
+    return (few && nq <= 2) ? (nq < 1 ? 1u : nq) : (nq <= 3 ? 3u : 5u);
+}
+
+// nq = scatter queues the scene needs (pool_scatter_queues); the LDS layout is that of the build that runs
 PoolConfig pool_config(uint32_t i, uint32_t nq)
 {
-    PoolConfig c = kPoolConfigs[i < pool_config_count() ? i : 0];
-    c.lds_bytes = (nq <= 3 ? pool_bytes_per_wave<3>(c.slots) : pool_bytes_per_wave<5>(c.slots)) * (c.threads / 64);
-    if (i == kTilePoolConfig)
-        c.lds_bytes = (nq <= 3 ? WavePoolLayout<kTilePoolSlots, 3, false, true>::kBytes : WavePoolLayout<kTilePoolSlots, 5, false, true>::kBytes) * (c.threads / 64);
+    if (i >= pool_config_count()) i = 0;
+    PoolConfig c = kPoolConfigs[i];
+    const uint32_t q = built_queues(i, nq);
+    const uint32_t per_wave = q == 1 ? pool_bytes_per_wave<1>(c.slots) : q == 2 ? pool_bytes_per_wave<2>(c.slots)
+                            : q == 3 ? pool_bytes_per_wave<3>(c.slots) : pool_bytes_per_wave<5>(c.slots);
+    c.lds_bytes = per_wave * (c.threads / 64);
+    if (i == kTilePoolConfig) {
+        const uint32_t tw = q == 1 ? WavePoolLayout<kTilePoolSlots, 1, false, true>::kBytes : q == 2 ? WavePoolLayout<kTilePoolSlots, 2, false, true>::kBytes
+                          : q == 3 ? WavePoolLayout<kTilePoolSlots, 3, false, true>::kBytes : WavePoolLayout<kTilePoolSlots, 5, false, true>::kBytes;
+        c.lds_bytes = tw * (c.threads / 64);
+    }
     return c;
 }
 
@@ -1574,8 +1601,12 @@ PoolConfig pool_config_grid(size_t lds_for_pools)
     return PoolConfig{ kGridPoolThreads, 0, 0 };
 }
 
-// builds exist for 3 and for 5 scatter queues; the counting build always has 5
-uint32_t pool_scatter_queues(uint32_t n_routines, bool count) { return (!count && n_routines <= 3) ? 3u : 5u; }
+// scatter queues a scene needs: one per shading routine (builds exist for 1, 2, 3 and 5); the counting build always has 5
+uint32_t pool_scatter_queues(uint32_t n_routines, bool count)
+{
+    if (count || n_routines > 3) return 5u;
+    return n_routines < 1 ? 1u : n_routines;
+}
 
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream)
 {
@@ -1587,7 +1618,7 @@ hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cf
     case 3:  return launch_pool_cfg<256, 256>(a, grid_blocks, count, hosek, nq, stream);
     case 4:  return launch_pool_cfg<256, 96, 7>(a, grid_blocks, count, hosek, nq, stream);     // 7 waves per SIMD: <= 72 VGPRs
     case kTilePoolConfig: return launch_pool_tile<256, kTilePoolSlots, 6>(a, grid_blocks, count, hosek, nq, stream);
-    default: return launch_pool_cfg<256, 112, 6>(a, grid_blocks, count, hosek, nq, stream);   // 6 waves per SIMD: <= 80 VGPRs
+    default: return launch_pool_cfg<256, 112, 6, true>(a, grid_blocks, count, hosek, nq, stream);   // 6 waves per SIMD: <= 80 VGPRs
     }
 }
 
@@ -1607,7 +1638,7 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
         case kTilePoolConfig: slots = kTilePoolSlots; break;
         default: break;
         }
-        if (count) { minw = 1; nq = 5; } else nq = (nq <= 3) ? 3 : 5;
+        if (count) { minw = 1; nq = 5; } else nq = built_queues(cfg, nq);
         if (cfg == kTilePoolConfig) {
             snprintf(out, out_len, "render_pt_pool_tile_kernel<%u,%u,%u,%s,%s,%u,false>", threads, slots, minw, tf[count], tf[hosek], nq);
             return;
