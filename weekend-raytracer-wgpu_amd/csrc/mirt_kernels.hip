@@ -1477,7 +1477,7 @@ uint32_t parity_blocks_per_cu(bool count, uint32_t lds_bytes)
 }
 #endif
 
-// builds of the pool kernel by scatter queues: 3 and 5 for every geometry; 1 and 2 as well (FEW = true) for the default and the
+// builds of the pool kernel by scatter queues: 3 and 5 for every geometry; 1, 2 and 4 as well (FEW = true) for the default and the
 // tile geometry -- a scene with fewer shading routines than queues would carry empty queues through every pick and push
 // (two routines, config 4: -1.2 %)
 template <uint32_t T, uint32_t SL, uint32_t MW = 1, bool FEW = false>
@@ -1495,6 +1495,8 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
                                   : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 1>, g, b, a, stream);
         if (nq == 2) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 2>, g, b, a, stream)
                                   : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 2>, g, b, a, stream);
+        if (nq == 4) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 4>, g, b, a, stream)
+                                  : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 4>, g, b, a, stream);
     }
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
@@ -1517,6 +1519,8 @@ static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bo
                               : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 1>, g, b, a, stream);
     if (nq == 2) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 2>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 2>, g, b, a, stream);
+    if (nq == 4) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 4>, g, b, a, stream)
+                              : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 4>, g, b, a, stream);
     if (nq <= 3) return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true, 3>, g, b, a, stream)
                               : launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, false, 3>, g, b, a, stream);
     return hosek ? launch_with_lds(render_pt_pool_tile_kernel<T, SL, MW, false, true>, g, b, a, stream)
@@ -1570,7 +1574,8 @@ static uint32_t pool_bytes_per_wave(uint32_t slots)
 static uint32_t built_queues(uint32_t cfg, uint32_t nq)
 {
     const bool few = cfg == kDefaultPoolConfig || cfg == kTilePoolConfig;
-    return (few && nq <= 2) ? (nq < 1 ? 1u : nq) : (nq <= 3 ? 3u : 5u);
+    if (few && nq >= 1 && nq <= 4) return nq;
+    return nq <= 3 ? 3u : 5u;
 }
 
 // nq = scatter queues the scene needs (pool_scatter_queues); the LDS layout is that of the build that runs
@@ -1580,11 +1585,12 @@ PoolConfig pool_config(uint32_t i, uint32_t nq)
     PoolConfig c = kPoolConfigs[i];
     const uint32_t q = built_queues(i, nq);
     const uint32_t per_wave = q == 1 ? pool_bytes_per_wave<1>(c.slots) : q == 2 ? pool_bytes_per_wave<2>(c.slots)
-                            : q == 3 ? pool_bytes_per_wave<3>(c.slots) : pool_bytes_per_wave<5>(c.slots);
+                            : q == 3 ? pool_bytes_per_wave<3>(c.slots) : q == 4 ? pool_bytes_per_wave<4>(c.slots) : pool_bytes_per_wave<5>(c.slots);
     c.lds_bytes = per_wave * (c.threads / 64);
     if (i == kTilePoolConfig) {
         const uint32_t tw = q == 1 ? WavePoolLayout<kTilePoolSlots, 1, false, true>::kBytes : q == 2 ? WavePoolLayout<kTilePoolSlots, 2, false, true>::kBytes
-                          : q == 3 ? WavePoolLayout<kTilePoolSlots, 3, false, true>::kBytes : WavePoolLayout<kTilePoolSlots, 5, false, true>::kBytes;
+                          : q == 3 ? WavePoolLayout<kTilePoolSlots, 3, false, true>::kBytes : q == 4 ? WavePoolLayout<kTilePoolSlots, 4, false, true>::kBytes
+                          : WavePoolLayout<kTilePoolSlots, 5, false, true>::kBytes;
         c.lds_bytes = tw * (c.threads / 64);
     }
     return c;
@@ -1601,10 +1607,10 @@ PoolConfig pool_config_grid(size_t lds_for_pools)
     return PoolConfig{ kGridPoolThreads, 0, 0 };
 }
 
-// scatter queues a scene needs: one per shading routine (builds exist for 1, 2, 3 and 5); the counting build always has 5
+// scatter queues a scene needs: one per shading routine (builds exist for 1 ... 5); the counting build always has 5
 uint32_t pool_scatter_queues(uint32_t n_routines, bool count)
 {
-    if (count || n_routines > 3) return 5u;
+    if (count || n_routines > 4) return 5u;
     return n_routines < 1 ? 1u : n_routines;
 }
 
