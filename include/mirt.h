@@ -135,8 +135,12 @@ enum {
     MIRT_FLAG_NO_TONEMAP     = 1u << 1, /* skip uncharted2 (wgsl:83-103) */
     MIRT_FLAG_NO_SRGB        = 1u << 2, /* skip the sRGB OETF the Bgra8UnormSrgb surface applies (main.rs:465) */
     MIRT_FLAG_COUNT_WORK     = 1u << 3, /* run the counting build of the kernel: fills MirtStats work counters */
-    /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the
-     * pooled kernel (paths queued by material in LDS) when spp >= 48, else the strip kernel. */
+    /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the pooled kernel
+     * (paths queued by shading routine in LDS) from a measured number of samples per pixel on -- 40 for scenes with
+     * several shading routines, 184 for scenes with one, 16 for many-sphere scenes (csrc/mirt_kernels.h, kPoolMinSpp*)
+     * -- and the strip kernel below (lane = pixel under 64 samples per pixel, else lane = sample).
+     * In parity mode MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule (default below 64 samples per pixel:
+     * lane = pixel, the shape of the reference's 2-spp operating point); the image is the same. */
     MIRT_FLAG_KERNEL_STRIP   = 1u << 4, /* force the strip kernel (wave = 64 samples of one pixel) */
     MIRT_FLAG_KERNEL_POOL    = 1u << 5, /* force the pooled kernel */
     MIRT_FLAG_NO_GRID        = 1u << 6, /* many-sphere scenes: scan the flat sphere list instead of the uniform grid */

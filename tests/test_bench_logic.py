@@ -52,7 +52,7 @@ def test_kernel_name_parsing():
     assert not bench.kernel_uses_grid("render_pt_pool_kernel<256,112,6,false,false,3,false>")
     assert bench.kernel_uses_grid("render_pt_strip_kernel<false,false,true,false>")
     assert not bench.kernel_uses_grid("render_pt_strip_kernel<false,false,false,true>")
-    assert not bench.kernel_uses_grid("render_parity_kernel<false>") and not bench.kernel_uses_grid("")
+    assert not bench.kernel_uses_grid("render_parity_kernel<false,false>") and not bench.kernel_uses_grid("")
 
 
 def test_every_baseline_config_has_a_bench_workload():

@@ -39,6 +39,28 @@ def test_layer_scene_vs_oracle(gpu_ctx, oracle, w, h, spp):
     assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), f"{w}x{h} spp{spp}")
 
 
+@pytest.mark.parametrize("w,h,spp", [(160, 120, 2), (333, 77, 21), (200, 150, 40), (17, 1, 2), (800, 600, 2)])
+def test_lane_per_pixel_and_lane_per_sample_schedules_agree(gpu_ctx, oracle, w, h, spp):
+    """Below 64 samples per pixel parity mode runs lane = pixel (every lane walks the reference's sample loop for its own
+    pixel, layer.rs:320-378); MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule.  Same image, same work counters,
+    and the kernel names say which one ran."""
+    sd = layer_scene_data(w, h)
+    gpu_ctx.set_scene(sd)
+    want = oracle.render(sd, m.make_params(w, h, spp))
+    by_pixel = gpu_ctx.render(m.make_params(w, h, spp))
+    assert gpu_ctx.last_kernel() == "render_parity_kernel<false,true>"
+    by_sample = gpu_ctx.render(m.make_params(w, h, spp, flags=m.MIRT_FLAG_KERNEL_STRIP))
+    assert gpu_ctx.last_kernel() == "render_parity_kernel<false,false>"
+    assert_images_equal(by_pixel, want, "lane = pixel")
+    assert_images_equal(by_sample, want, "lane = sample")
+    counts = []
+    for extra in (0, m.MIRT_FLAG_KERNEL_STRIP):
+        assert_images_equal(gpu_ctx.render(m.make_params(w, h, spp, flags=m.MIRT_FLAG_COUNT_WORK | extra)), want, "counting build")
+        st = gpu_ctx.stats()
+        counts.append({k: st[k] for k in COUNTED} | {"scatter_metal": st["scatter"][1]})
+    assert counts[0] == counts[1]
+
+
 def test_k1_empty_world(gpu_ctx):
     w, h = 97, 53
     sd = m.SceneData(simple_camera(w, h), [], [], np.zeros((0, 3), np.float32))

@@ -55,6 +55,30 @@ def test_pt_vs_oracle_images_and_counters(gpu_ctx, oracle, scene, w, h, spp, fla
     assert_images_equal(gpu_ctx.render(p2), want, "plain build")
 
 
+@pytest.mark.parametrize("eye", [(0.0, 0.0, 3.0), (-0.0, 0.0, 3.0), (0.5, -0.0, 3.0), (1.5, 0.25, 3.0)])
+@pytest.mark.parametrize("kernel,spp", [(m.MIRT_FLAG_KERNEL_STRIP, 6), (m.MIRT_FLAG_KERNEL_STRIP, 70), (m.MIRT_FLAG_KERNEL_POOL, 70)])
+def test_pinhole_cameras_skip_the_lens_exactly(gpu_ctx, oracle, eye, kernel, spp):
+    """Aperture 0 (BASELINE configs 2 and 4): the kernels take `origin = eye` without evaluating the lens disc, which is
+    exact unless an eye component is -0 (then the host leaves the shortcut off); the two lens draws are still consumed.
+    The oracle always evaluates the full thin-lens formula (wgsl:456-478).  Eye components of +0 and -0 included; the
+    sphere sits on the axes so that hit points with exactly-zero components occur."""
+    w, h = 96, 64
+    sc, _, mats, tex = __import__("helpers")._flattened("three_spheres")
+    cam = simple_camera(w, h, eye=eye, direction=(0.0, 0.0, -1.0), vfov=50.0, aperture=0.0, focus=3.0)
+    assert cam.lens_radius == 0.0
+    spheres = [m.Sphere.new((0.0, 0.0, 0.0), 1.0, 2).to_c(), m.Sphere.new((0.0, -101.0, 0.0), 100.0, 0).to_c(),
+               m.Sphere.new((1.5, 0.0, 0.5), 0.5, 1).to_c()]
+    sd = m.SceneData(cam, spheres, list(mats), tex)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=kernel | m.MIRT_FLAG_COUNT_WORK)
+    got = _render(gpu_ctx, sd, p)
+    gs = gpu_ctx.stats()
+    want = oracle.render(sd, p)
+    os_ = oracle.stats()
+    assert_images_equal(got, want, f"pinhole eye {eye} spp {spp}")
+    assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+    assert_images_equal(gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=kernel)), want, "plain build")
+
+
 @pytest.mark.parametrize("bounces", [0, 1, 2, 4, 10, 300])
 @pytest.mark.parametrize("kernel", [m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
 def test_bounce_limits(gpu_ctx, oracle, bounces, kernel):

@@ -198,6 +198,7 @@ struct Tuning {
     uint32_t pool_blocks_per_cu = 0;  // MIRT_POOL_BLOCKS_PER_CU: fewer resident pool blocks (occupancy experiments)
     double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
     double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
+    int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
 };
 
 Tuning read_tuning()
@@ -211,8 +212,22 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_BY_PIXEL")) t.by_pixel = (e[0] == '1') ? 1 : 0;
     if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
     if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
+    if (const char* e = std::getenv("MIRT_PINHOLE")) t.pinhole = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
+}
+
+// A camera whose thin-lens offset is exactly zero for every lens draw, so that `origin = eye + lens_radius * (...)`
+// (wgsl:468-472) is `eye` bit for bit: lens_radius == +-0 (aperture 0: GpuCamera::new mod.rs:705), a finite lens basis and a
+// finite eye without a -0 component (see generate_primary in mirt_kernels.hip for the argument).
+bool camera_is_pinhole(const MirtGpuCamera& cam)
+{
+    if (cam.lens_radius != 0.0f) return false;
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(cam.u[k]) || !std::isfinite(cam.v[k]) || !std::isfinite(cam.eye[k])) return false;
+        if (cam.eye[k] == 0.0f && std::signbit(cam.eye[k])) return false;
+    }
+    return true;
 }
 
 template <typename T>
@@ -695,7 +710,11 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const uint32_t resident_pool_waves = pool_grid ? pool_grid_waves_per_cu : pool_waves_per_cu;
 
     mirt::RenderArgs a{};
-    a.cam = c->cam; a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
+    a.cam = c->cam;
+    // the kernels' pinhole shortcut (generate_primary): the flag travels in the padding word beside lower_left_corner of
+    // THIS launch's by-value copy of the camera; the caller's struct is never touched
+    { const uint32_t flag = (pt && tune.pinhole != 0 && camera_is_pinhole(c->cam)) ? 1u : 0u; std::memcpy(&a.cam._padding5, &flag, 4); }
+    a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
     a.out = d_out; a.counters = c->d_counters + ev * mirt::kNumCounters; a.work_counter = c->d_work_counter + ev; a.accum = d_accum;
     a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
@@ -760,10 +779,12 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool by_pixel = pt && !pool && !count && (p->spp < mirt::kByPixelMaxSpp || (c->n_shading_routines <= 1 && npix >= 64ull * 4u * c->cu_count));
     if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
     if (frame_stream) by_pixel = true;                    // also for counting launches (flat scan) and any spp
+    // parity mode at the reference's operating point (2 samples per pixel, mod.rs:605-613): lane = pixel as well, counting or not
+    if (!pt) by_pixel = (p->flags & MIRT_FLAG_KERNEL_STRIP) ? false : (tune.by_pixel >= 0 ? tune.by_pixel == 1 : p->spp < mirt::kByPixelMaxSpp);
     a.static_units = 0;
     if (by_pixel) {
         a.n_units = (uint32_t)((npix + 63u) / 64u);
-        a.static_units = p->spp < 8u ? 1u : 0u;           // measured crossover (tools/low_spp.py)
+        a.static_units = (pt && p->spp < 8u) ? 1u : 0u;   // measured crossover (tools/low_spp.py); the parity kernel always dispenses
     }
 
     uint32_t blocks;
@@ -783,7 +804,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // a persistent grid of exactly the blocks that are resident at once: registers and LDS decide (4-8 per CU for these
         // kernels).  A block beyond that would hold its first unit until the dispenser has run dry and run it alone at the end.
         const bool fast_strip = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
-        uint32_t per_cu = !pt ? kx::parity_blocks_per_cu(count, a.lds_bytes)
+        uint32_t per_cu = !pt ? kx::parity_blocks_per_cu(count, by_pixel, a.lds_bytes)
                         : fast_strip ? kf::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes)
                                      : kx::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes);
         if (per_cu > 8u) per_cu = 8u;                                 // 2048 threads per CU / 256
@@ -802,8 +823,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const char* tf[2] = { "false", "true" };
     char kname[112] = "";
     if (p->mode == MIRT_MODE_PARITY) {
-        HIP_TRY(kx::launch_parity(a, blocks, count, stream));
-        snprintf(c->last_kernel, sizeof c->last_kernel, "render_parity_kernel<%s>", tf[count]);
+        HIP_TRY(kx::launch_parity(a, blocks, count, by_pixel, stream));
+        snprintf(c->last_kernel, sizeof c->last_kernel, "render_parity_kernel<%s,%s>", tf[count], tf[by_pixel]);
     } else if (pool) {
         HIP_TRY(fast ? kf::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream) : kx::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
         kx::pool_kernel_name(a, pool_cfg, count, pool_nq, kname, sizeof kname);

@@ -159,11 +159,11 @@ uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pi
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
 }
 namespace exact_build {
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream);
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, hipStream_t stream);
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
 // blocks of the kernel such a launch runs that are resident per CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes);
-uint32_t   parity_blocks_per_cu(bool count, uint32_t lds_bytes);
+uint32_t   parity_blocks_per_cu(bool count, bool by_pixel, uint32_t lds_bytes);
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
 PoolConfig pool_config_grid(size_t lds_for_pools);   // grid build: slots by the LDS left beside scene + grid (slots = 0: none fits)

@@ -11,7 +11,8 @@
 //   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
 //                          paths in LDS, queued by the shading routine they wait for, and always
 //                          runs ONE routine on up to 64 of them — the material switch no longer
-//                          serialises inside a wave (default for spp >= 48).
+//                          serialises inside a wave (default from 40 / 184 / 16 samples per pixel on for scenes
+//                          with several / one shading routine / many spheres: mirt_kernels.h, kPoolMinSpp*).
 //
 // Every pixel's radiance is summed in 64-bit fixed point (exact, order-independent), so the three
 // schedules — and any GPU count — give bit-identical images.
@@ -192,9 +193,9 @@ MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height,
     const uint32_t j = sat_u32(uc * (float)width);
     const uint32_t i = sat_u32(vf * (float)height);
     const uint32_t idx = i * width + j;
-#ifdef MIRT_PROBE_NOFETCH    // experiment: the whole lookup EXCEPT the memory access -> the ceiling of any texel cache
-    return mk(from_bits(0x3e800000u | (idx & 1u)), 0.4f, 0.5f);
-#else
+#define MIRT_PROBE_SITE 0           // experiment builds only: expands to nothing in libmirt.so
+#include "mirt_pool_probes.inc"
+#undef MIRT_PROBE_SITE
     if (T == nullptr) return texel_at(A, (uint64_t)offset + (uint64_t)idx);
     // ---- tile build: runs in the lanes of a wave that need an image texel (a divergent region) ----
     uint4 hd = make_uint4(T->j0, T->i0, T->off, T->w);                          // scalar registers
@@ -231,7 +232,6 @@ MIRT_DEV f3 texture_lookup(const RenderArgs& A, uint32_t width, uint32_t height,
         if (!in) c = texel_at(A, (uint64_t)offset + (uint64_t)idx);
     }
     return c;
-#endif
 }
 
 MIRT_DEV unsigned long long wave_sum_u64(unsigned long long v)
@@ -316,7 +316,11 @@ MIRT_DEV bool parity_world_hit(const SceneLds& S, uint32_t n_spheres, const PRay
 // COUNT = true additionally tallies the work the REFERENCE's sequential sample loop performs (it returns at
 // the first terminating sample): only the samples up to and including that one are counted, although all 64
 // lanes of a batch compute theirs.  The CPU check in tests/test_gpu_parity.py tallies the same quantities.
-template <bool COUNT>
+// BY_PIXEL = false: a wave owns a strip of 16 pixels and takes them one at a time, lane = sample (64 samples of a pixel per batch).
+// BY_PIXEL = true : a wave owns 64 consecutive pixels, lane = pixel, and every lane runs the reference's sample loop for its pixel
+//                   in order -- the launch shape for the reference's operating point, 2 samples per pixel (mod.rs:605-613), where
+//                   lane = sample would leave 62 of 64 lanes idle.  The host takes it below kByPixelMaxSpp samples per pixel.
+template <bool COUNT, bool BY_PIXEL = false>
 __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -334,6 +338,73 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
     work.clear();
 
     for (uint32_t strip = first_unit(); strip < A.n_units; strip = next_unit(A, lane)) {
+        if constexpr (BY_PIXEL) {
+            const uint32_t pi = strip * 64u + lane;
+            const bool inside = pi < npix;
+            const uint32_t ci = (inside ? pi : 0u) / A.width;
+            const uint32_t x = (inside ? pi : 0u) - ci * A.width;
+            const uint32_t y = abs_row(A, ci);
+            const float u = (float)x / wf;               // coord_to_color math.rs:4-9
+            const float v = (float)y / hf;
+            uint32_t hits_before = 0;                    // primary hits of this pixel's earlier samples: `depth` = 20 - hits_before
+            bool done = !inside;
+            uint32_t rgba = pack_rgba(sat_u8(v * 255.0f), sat_u8(u * 255.0f), sat_u8(255.0f));   // loop exhausted: layer.rs:380
+            for (uint32_t s = 0; s < A.spp && ballot_(!done) != 0ull; ++s) {      // the sample loop layer.rs:320-378, every lane its own
+                const bool active = !done;
+                const float uu = u + 0.0f, vv = v + 0.0f;                          // jitter == +0.0f (see the lane = sample loop below)
+                PRay ray;
+                ray.o = eye;
+                ray.d = ((llc + uu * hor) + vv * ver) - eye;                       // GpuCamera::make_ray mod.rs:745-754
+                PHit rec;
+                rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0);
+                bool prim = false, scat_ok = false, sec = false;
+                f3 colour = mk(0, 0, 0);
+                PCount pc1{}, pc2{};
+                if (active) prim = parity_world_hit<COUNT>(S, A.n_spheres, ray, 0.001f, FMAX, FMAX, rec, pc1);
+                const bool exhausted = prim && (hits_before >= 20u);                // `if depth <= 0 { return black }` layer.rs:333-335
+                if (prim) {
+                    const MirtMaterial m2 = S.mats[2];                              // index 2, screen-space (uu, vv): layer.rs:345-351
+                    const float fuzzy = m2.x;
+                    const f3 albedo = texture_lookup(A, m2.desc1.width, m2.desc1.height, m2.desc1.offset, uu, vv);
+                    const f3 unit = mk(ray.d.x / 3.0f, ray.d.y / 3.0f, ray.d.z / 3.0f);     // unit_vertor math.rs:147-149
+                    const float k = 2.0f * dot_nofma(unit, rec.n);                  // reflect math.rs:154-159
+                    PRay sc;
+                    sc.o = rec.p;
+                    sc.d = unit - k * rec.n;
+                    scat_ok = dot_nofma(sc.d, rec.n) > 0.0f;                        // scatter_metal mod.rs:1292-1315
+                    if (scat_ok && !exhausted) {
+                        sec = parity_world_hit<COUNT>(S, A.n_spheres, sc, 0.001f, FMAX, FMAX, rec, pc2);
+                        if (sec) {
+                            const float norm = sqrt_(dot_nofma(rec.n, rec.n));      // layer.rs:364-372
+                            f3 c = mk(rec.n.x / norm, rec.n.y / norm, rec.n.z / norm);
+                            c = mk((c.x * 255.0f) / 2.0f, (c.y * 255.0f) / 2.0f, (c.z * 255.0f) / 2.0f);
+                            c = mk(c.x * (albedo.x * fuzzy), c.y * (albedo.y * fuzzy), c.z * (albedo.z * fuzzy));
+                            colour = mk(0.0f + c.x, 0.0f + c.y, 0.0f + c.z);
+                        }
+                    }
+                }
+                const bool term = prim && (exhausted || !scat_ok || sec);          // this sample returns from the pixel
+                if (term) {
+                    rgba = (exhausted || !scat_ok) ? pack_rgba(0, 0, 0) : pack_rgba(sat_u8(colour.x), sat_u8(colour.y), sat_u8(colour.z));
+                    done = true;
+                }
+                hits_before += prim ? 1u : 0u;
+                if constexpr (COUNT) {
+                    if (active) {
+                        const bool second = prim && !exhausted && scat_ok;
+                        work.add(kCntLaneIters);
+                        work.add(kCntRays, second ? 2u : 1u);
+                        work.add(kCntTests, pc1.tests + (second ? pc2.tests : 0u));
+                        work.add(kCntRoots, pc1.roots + (second ? pc2.roots : 0u));
+                        work.add(kCntHits, pc1.hits + (second ? pc2.hits : 0u));
+                        if (prim && !exhausted) work.add(kCntScatter1);
+                    }
+                }
+            }
+            if (inside) A.out[pi] = rgba;
+            work.flush(A.counters, lane);
+            continue;
+        }
         const uint32_t base = strip * kStripPixels;
         uint32_t my_px = 0;
         for (uint32_t p = 0; p < kStripPixels; ++p) {
@@ -457,12 +528,21 @@ struct Rng {
         state = (word >> 22) ^ word;
         return (float)state * c_times_2m32;
     }
+    // a draw whose value is not used: the state advances, nothing is converted
+    MIRT_DEV void skip()
+    {
+        const uint32_t old = state + 747796405u + 2891336453u;
+        const uint32_t word = ((old >> ((old >> 28) + 4u)) ^ old) * 277803737u;
+        state = (word >> 22) ^ word;
+    }
 };
 
 // camera constants hoisted into registers once per thread
 struct CamRegs {
-    f3 eye, hor, ver, cam_u, cam_v, llc;
-    float lens_radius, inv_w, inv_h;
+    f3 eye, hor, ver, llc;
+    const float* cam;          // LDS: lens basis and radius are read where a thin lens needs them
+    bool pinhole;              // wave-uniform: the lens offset is exactly zero for every draw (see generate_primary)
+    float inv_w, inv_h;
 };
 
 MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
@@ -473,10 +553,11 @@ MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
     c.eye = mk(S.cam[0], S.cam[1], S.cam[2]);
     c.hor = mk(S.cam[4], S.cam[5], S.cam[6]);
     c.ver = mk(S.cam[8], S.cam[9], S.cam[10]);
-    c.cam_u = mk(S.cam[12], S.cam[13], S.cam[14]);
-    c.cam_v = mk(S.cam[16], S.cam[17], S.cam[18]);
-    c.lens_radius = S.cam[19];
     c.llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    // RenderArgs.cam._padding5 is written by the host for every launch (launch_render): 1 = pinhole.  All lanes read the
+    // same LDS word; readfirstlane tells the compiler so.
+    c.pinhole = __builtin_amdgcn_readfirstlane(bits(S.cam[23])) != 0u;
+    c.cam = S.cam;
     c.inv_w = 1.0f / (float)A.width;
     c.inv_h = 1.0f / (float)A.height;
     return c;
@@ -485,6 +566,11 @@ MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
 // initRng (wgsl:498-502, frame = sample + 1) + samplePixel (wgsl:114-117) + cameraMakeRay (wgsl:456-478)
 // RESEED = false continues the caller's stream: the reference's samplePixel loop draws all samples of one frame from
 // the stream initRng seeded once for that frame (MirtParams.frame_spp > 0; lane-per-pixel schedule only).
+// PINHOLE cameras (aperture 0: BASELINE configs 2 and 4, every camera of the reference's CPU path) skip the lens, EXACTLY:
+// with lens_radius == +-0 both offsets lpx, lpy are +-0 (lr in [0, 1], sin / cos finite), so for a finite lens basis
+// fma(lpy, v_k, lpx * u_k) = +-0, and eye_k + (+-0) == eye_k bit for bit unless eye_k is -0 (then the sum's sign would
+// depend on the draw).  The host sets the flag only when lens_radius == 0, eye / u / v are finite and no eye component is
+// -0 (mirt_api.hip: camera_is_pinhole); the two lens draws are still consumed, so the stream is the reference's.
 template <bool RESEED = true>
 MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x, uint32_t y, uint32_t sample,
                                Rng& rng, f3& ro, f3& rd)
@@ -495,11 +581,21 @@ MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x
     }
     const float u = ((float)x + rng.next()) * C.inv_w;
     const float v = 1.0f - ((float)y + rng.next()) * C.inv_h;
-    const float lr = sqrt_unit(rng.next());
-    const SinCos la = sincos_small(rng.next_scaled(kTwoPi * 0x1p-32f));
-    const float lpx = C.lens_radius * (lr * la.c);
-    const float lpy = C.lens_radius * (lr * la.s);
-    ro = C.eye + fma3(lpy, C.cam_v, lpx * C.cam_u);
+    if (C.pinhole) {
+        asm volatile("; generate_primary: pinhole camera" ::);       // keeps this a real (scalar) branch
+        rng.skip();
+        rng.skip();
+        ro = C.eye;
+    } else {
+        const f3 cam_u = mk(C.cam[12], C.cam[13], C.cam[14]);
+        const f3 cam_v = mk(C.cam[16], C.cam[17], C.cam[18]);
+        const float lens_radius = C.cam[19];
+        const float lr = sqrt_unit(rng.next());
+        const SinCos la = sincos_small(rng.next_scaled(kTwoPi * 0x1p-32f));
+        const float lpx = lens_radius * (lr * la.c);
+        const float lpy = lens_radius * (lr * la.s);
+        ro = C.eye + fma3(lpy, cam_v, lpx * cam_u);
+    }
     rd = fma3(v, C.ver, fma3(u, C.hor, C.llc)) - ro;
 }
 
@@ -1122,11 +1218,14 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
     for (uint32_t strip = first_unit(); strip < A.n_units;
          strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit(A, lane)) {
         if constexpr (BY_PIXEL) {
+            // arguments needed once per unit are read from the kernarg segment here and now (per_strip_args) instead of
+            // living in SGPRs across the sample loop, which the 8-waves-per-SIMD build has too few of
+            const RenderArgs& AP = per_strip_args();
             const uint32_t pi = strip * 64u + lane;
-            const bool inside = pi < npix;
-            const uint32_t ci = (inside ? pi : 0u) / A.width;
-            const uint32_t x = (inside ? pi : 0u) - ci * A.width;
-            const uint32_t y = abs_row(A, ci);
+            const bool inside = pi < AP.out_rows * AP.width;
+            const uint32_t ci = (inside ? pi : 0u) / AP.width;
+            const uint32_t x = (inside ? pi : 0u) - ci * AP.width;
+            const uint32_t y = abs_row(AP, ci);
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
             Rng rng;
             rng.state = 0;
@@ -1149,11 +1248,12 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
                 acc_b += to_fixed(c.z);
             }
             if (inside) {
-                if (A.accum) {                   // progressive mode: add the exact sums, resolve later
-                    A.accum[3ull * pi + 0] += acc_r; A.accum[3ull * pi + 1] += acc_g; A.accum[3ull * pi + 2] += acc_b;
+                const RenderArgs& AS = per_strip_args();
+                if (AS.accum) {                  // progressive mode: add the exact sums, resolve later
+                    AS.accum[3ull * pi + 0] += acc_r; AS.accum[3ull * pi + 1] += acc_g; AS.accum[3ull * pi + 2] += acc_b;
                 } else {
-                    A.out[pi] = pack_rgba(resolve_channel(acc_r, A.spp, A.flags), resolve_channel(acc_g, A.spp, A.flags),
-                                          resolve_channel(acc_b, A.spp, A.flags));
+                    AS.out[pi] = pack_rgba(resolve_channel(acc_r, AS.spp, AS.flags), resolve_channel(acc_g, AS.spp, AS.flags),
+                                           resolve_channel(acc_b, AS.spp, AS.flags));
                 }
             }
         } else {
@@ -1266,41 +1366,8 @@ struct WavePoolLayout {
 #undef MIRT_POOL_KERNEL_TILE
 
 #ifdef MIRT_ISA_PROBES
-// ------------------------------------------------------------------------------------------
-// ISA probes (tools/isa_mix.py, never part of libmirt.so): one kernel per routine of the path-traced mode, each
-// around the SAME load / store frame (probe_frame = that frame alone), so that the instruction mix of a routine can be
-// read off the compiler's assembly in isolation.  Inputs come from memory and every result is stored: nothing folds.
-// ------------------------------------------------------------------------------------------
-struct ProbeIo { float4 a, b, c; uint4 u; };
-
-#define MIRT_PROBE_KERNEL(NAME, BODY)                                                                              \
-    __global__ __launch_bounds__(256) void NAME(RenderArgs A, const ProbeIo* in, ProbeIo* out)                       \
-    {                                                                                                              \
-        extern __shared__ __align__(16) unsigned char smem[];                                                      \
-        const SceneLds S = stage_scene<true, true>(A, smem, false);                                                \
-        ProbeIo io = in[blockIdx.x * 256 + threadIdx.x];                                                           \
-        f3 ro = mk(io.a.x, io.a.y, io.a.z), rd = mk(io.b.x, io.b.y, io.b.z), hn = mk(io.c.x, io.c.y, io.c.z);    \
-        f3 o0 = ro, o1 = rd;                                                                                       \
-        Rng rng; rng.state = io.u.x;                                                                               \
-        Work<false> work; (void)work; (void)S; (void)hn;                                                           \
-        BODY                                                                                                       \
-        io.a = make_float4(o0.x, o0.y, o0.z, io.a.w); io.b = make_float4(o1.x, o1.y, o1.z, io.b.w); io.u.x = rng.state;          \
-        out[blockIdx.x * 256 + threadIdx.x] = io;                                                                  \
-    }
-
-MIRT_PROBE_KERNEL(probe_frame, { })
-MIRT_PROBE_KERNEL(probe_rng_4_variates, { o0.x = rng.next(); o0.y = rng.next(); o0.z = rng.next(); o1.x = rng.next(); })
-MIRT_PROBE_KERNEL(probe_generate_primary, { const CamRegs C = load_camera(S, A); generate_primary(A, C, io.u.y, io.u.z, io.u.w, rng, o0, o1); })
-MIRT_PROBE_KERNEL(probe_nearest_hit_3_spheres, { float closest; const int nb = nearest_hit<false>(S, 3u, ro, rd, io.u.y != 0u, closest, work);
-                                                  o0 = fma3(closest, rd, ro); io.u.z = (uint32_t)nb; })
-MIRT_PROBE_KERNEL(probe_shade_lambertian, { shade_lambertian(A, &S.pmats[io.u.y], hn, rng, o0, o1); })
-MIRT_PROBE_KERNEL(probe_shade_checkerboard, { shade_checkerboard(A, &S.pmats[io.u.y], ro, hn, rng, o0, o1); })
-MIRT_PROBE_KERNEL(probe_shade_metal, { shade_metal(A, &S.pmats[io.u.y], rd, hn, rng, o0, o1); })
-MIRT_PROBE_KERNEL(probe_shade_dielectric, { shade_dielectric(&S.pmats[io.u.y], rd, hn, rng, o0, o1); })
-MIRT_PROBE_KERNEL(probe_sky_and_accumulate, { const f3 c = sky_color<false>(S, rd);
-                                              io.u.y = to_fixed(ro.x * c.x); io.u.z = to_fixed(ro.y * c.y); io.u.w = to_fixed(ro.z * c.z); })
-MIRT_PROBE_KERNEL(probe_hit_normal, { const PreparedSphere sp = S.spheres[io.u.y]; o0 = sp.inv_r * (ro - mk(sp.cx, sp.cy, sp.cz)); io.u.z = sp.material_idx; })
-#endif  // MIRT_ISA_PROBES
+#include "mirt_isa_probes.inc"       // tools/isa_mix.py; never part of libmirt.so
+#endif
 
 #ifndef MIRT_FAST_MATH       // self-test, resolve and de-interleave live in the exact build only
 // ------------------------------------------------------------------------------------------
@@ -1405,10 +1472,16 @@ static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a,
 }
 
 #ifndef MIRT_FAST_MATH
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, hipStream_t stream)
+using ParityKernel = void (*)(RenderArgs);
+static ParityKernel parity_kernel(bool count, bool by_pixel)
 {
-    return count ? launch_with_lds(render_parity_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), a, stream)
-                 : launch_with_lds(render_parity_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
+    if (by_pixel) return count ? render_parity_kernel<true, true> : render_parity_kernel<false, true>;
+    return count ? render_parity_kernel<true, false> : render_parity_kernel<false, false>;
+}
+
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, hipStream_t stream)
+{
+    return launch_with_lds(parity_kernel(count, by_pixel), dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
 
 #endif
@@ -1470,10 +1543,9 @@ uint32_t strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixe
 }
 
 #ifndef MIRT_FAST_MATH
-uint32_t parity_blocks_per_cu(bool count, uint32_t lds_bytes)
+uint32_t parity_blocks_per_cu(bool count, bool by_pixel, uint32_t lds_bytes)
 {
-    return count ? blocks_per_cu(reinterpret_cast<const void*>(render_parity_kernel<true>), kBlockThreads, lds_bytes)
-                 : blocks_per_cu(reinterpret_cast<const void*>(render_parity_kernel<false>), kBlockThreads, lds_bytes);
+    return blocks_per_cu(reinterpret_cast<const void*>(parity_kernel(count, by_pixel)), kBlockThreads, lds_bytes);
 }
 #endif
 
