@@ -24,8 +24,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 on a bounded sample of the same workload (rank 0, N = 1 only), plus `layer_rs`: the reference's
                 own CPU loop (`Layer::set_data`, parity mode) restated, faithful (with its per-sample
                 world.clone() allocations) and clean, on 1 thread and on all cores.
-  verified_rows rows of the frame the timed region produced, compared byte for byte with oracle rows rendered at
-                the full sample count (the checker, after the clock has stopped).
+  verified_rows rows of the frame the timed region produced -- for N > 1 the frame GATHERED over RCCL on rank 0 --
+                compared byte for byte with oracle rows rendered at the full sample count (the checker, after the
+                clock has stopped).  Bands of rows around a few probe rows, so that the checker uses the host's cores.
+  gather_ms     N > 1: one gather + de-interleave on its own (no render), timed after the timed region.
 
 `--dry-run` rehearses the N-rank path without a GPU (gloo, CPU tensors, a pattern renderer instead of the HIP
 kernel): it proves that the ranks start, partition, gather and assemble; it measures nothing.
@@ -128,6 +130,53 @@ def kernel_uses_grid(name: str) -> bool:
     return False
 
 
+def kernel_schedule(name: str) -> str:
+    """What decides a kernel's lane utilisation: its family and its lane mapping ("pool", "strip/pixel", "strip/sample", ...)."""
+    if "<" not in name:
+        return name
+    fam = name[:name.index("<")].replace("fast_build::", "")
+    targs = name[name.index("<") + 1:name.rindex(">")].split(",")
+    if fam == "render_pt_strip_kernel":
+        return "strip/pixel" if targs[3] == "true" else "strip/sample"
+    if fam == "render_parity_kernel":
+        return "parity/pixel" if len(targs) > 1 and targs[1] == "true" else "parity/sample"
+    return "pool" if fam.startswith("render_pt_pool") else fam
+
+
+def algorithmic_bytes(sd, mode: str, out_bytes: int) -> int:
+    """HBM bytes the workload needs per launch: the framebuffer once, the camera, the sphere and material tables
+    once, and the texels of the textures the launch can READ -- image textures (larger than 1x1) of materials some sphere
+    uses in path-traced mode (1x1 colours travel inside the prepared material table), the one or two texels of
+    material_data[2].desc1 in parity mode (layer.rs:345-351 and the row-0 quirk).  Not the whole texel table: config 3
+    never reads a texel (8 294 752 B)."""
+    tables = 96 + 32 * len(sd.spheres) + 32 * len(sd.materials)
+    if mode == "parity":
+        return out_bytes + tables + 2 * 12
+    seen, texel_bytes = set(), 0
+    for s in sd.spheres:
+        if s.material_idx >= len(sd.materials):
+            continue
+        mat = sd.materials[s.material_idx]
+        for d in (mat.desc1, mat.desc2):
+            key = (d.width, d.height, d.offset)
+            if d.width * d.height > 1 and d.offset != 0xffffffff and key not in seen:
+                seen.add(key)
+                texel_bytes += 12 * d.width * d.height
+    return out_bytes + tables + texel_bytes
+
+
+def rank_device_error(world: int, n_devices: int, dry: bool):
+    """(exit code, one-line message) if this process cannot run as one of `world` ranks with `n_devices` visible GPUs."""
+    if dry:
+        return None
+    if n_devices == 0:
+        return 3, "bench.py: no GPU visible; the render path has no CPU fallback (use --dry-run to rehearse the rank plumbing)"
+    if world > n_devices:
+        return 2, (f"bench.py: --gpus {world} needs {world} GPUs, {n_devices} visible: one rank per GPU "
+                   f"(RCCL refuses two ranks on one device)")
+    return None
+
+
 def build_scene(m, cfg: dict):
     w, h = cfg["width"], cfg["height"]
     if cfg["scene"] == "layer_scene":                     # Layer::new + set_global_data under the default fly camera
@@ -161,7 +210,7 @@ def cpu_baseline(m, sd, cfg: dict, target_seconds: float = 12.0) -> dict:
     cores = host_cores()
     w, h, full = cfg["width"], cfg["height"], cfg["spp"]
     if cfg["mode"] == "parity":
-        lr = layer_rs_baseline(m, ob, sd, w, h)
+        lr = layer_rs_baseline(m, ob, sd, w, h, spp=full if full < 64 else 2)
         best = lr["clean_all_cores"]
         return {"value": best["msamples_per_s"], "unit": "Msamples/s", "cores": cores, "kind": "port",
                 "sample": f"Layer::scene {w}x{h} at {lr['spp']} spp (the reference's default), clean variant on all cores; see layer_rs",
@@ -268,20 +317,100 @@ def texel_tiles_line(m, torch, ctx, base, default_frame, total_samples: int, lau
             "note": "opt-in build: a 16x2-texel LDS window per wave and strip; same texel values, so the same image; not the reported value"}
 
 
-def verify_rows(m, sd, cfg: dict, frame_host, budget_seconds: float = 40.0) -> list:
-    """Rows of the TIMED frame against oracle rows at the full sample count; the checker runs after the clock stopped."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import numpy as np
-    import oracle_binding as ob
+def steady_state_line(m, torch, ctx, base, w: int, h: int, spp: int = 1000, launches: int = 3) -> dict:
+    """Config 2's frame lasts 1.4 ms: ramp-up and tail weigh.  The same scene at 1000 spp, outside the timed region, separates the
+    kernel's steady-state rate from that (default schedule for that sample count; flops from a counting launch of its own)."""
+    import copy
+    p = copy.copy(base)
+    p.spp = spp
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.render_device(p, out.data_ptr(), out.numel(), stream)            # warm-up
+    torch.cuda.synchronize()
+    ctx.stats()
+    for _ in range(launches):
+        ctx.render_device(p, out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    ms = st["kernel_ms_total"] / max(1, st["launches"])
+    kernel = ctx.last_kernel()
+    pc = copy.copy(p)
+    pc.flags |= m.MIRT_FLAG_COUNT_WORK
+    ctx.render_device(pc, out.data_ptr(), out.numel(), stream)
+    torch.cuda.synchronize()
+    flops = algorithmic_flops(ctx.stats(), mode="pt")
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"spp": spp, "kernel": kernel, "kernel_ms_avg": round(ms, 4), "value_from_kernel_time": round(w * h * spp / ms / 1e3, 2),
+            "unit": "Msamples/s", "roofline_frac": round(tf / PEAK_FP32_VECTOR_TFLOPS, 4),
+            "note": "same scene and frame at 1000 spp, outside the timed region: the rate without the ramp-up and tail of a 1.4 ms launch"}
 
+
+def parity_schedules_line(m, torch, ctx, base, w: int, h: int, launches: int = 20) -> dict:
+    """Parity mode's two schedules on this workload, outside the timed region: lane = pixel (default below 64 spp, the shape of the
+    reference's 2-spp operating point) and lane = sample (MIRT_FLAG_KERNEL_STRIP), kernel time from HIP events, frames compared."""
+    import copy
+    out, frames = {}, []
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, extra in (("default", 0), ("lane_per_sample_forced", m.MIRT_FLAG_KERNEL_STRIP)):
+        p = copy.copy(base)
+        p.flags |= extra
+        buf = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+        ctx.render_device(p, buf.data_ptr(), buf.numel(), stream)
+        torch.cuda.synchronize()
+        ctx.stats()
+        for _ in range(launches):
+            ctx.render_device(p, buf.data_ptr(), buf.numel(), stream)
+        torch.cuda.synchronize()
+        st = ctx.stats()
+        ms = st["kernel_ms_total"] / max(1, st["launches"])
+        frames.append(buf)
+        out[name] = {"kernel": ctx.last_kernel(), "kernel_us_avg": round(ms * 1e3, 2), "msamples_per_s": round(w * h * base.spp / ms / 1e3, 1)}
+    out["frames_identical"] = bool(torch.equal(frames[0], frames[1]))
+    return out
+
+
+def verify_rows(m, sd, cfg: dict, frame_host, budget_seconds: float = 40.0, cpu_msamples_per_s: float = None, oracle_rows=None) -> list:
+    """Rows of the TIMED frame against oracle rows at the full sample count; the checker runs after the clock stopped.
+    The oracle parallelises over rows, so every probe is a BAND of rows (up to 16, one per host thread) around a probe row
+    -- the middle of the frame first.  `cpu_msamples_per_s` (the cpu_baseline leg's rate on all cores) sizes the number of
+    bands to the budget before anything is rendered; the budget is checked again between bands.  `oracle_rows(first, last)`
+    replaces the CPU oracle (the dry run's pattern)."""
+    import numpy as np
+
+    w, h = cfg["width"], cfg["height"]
+    cores = host_cores()
+    band = max(1, min(16, cores, h))
+    probes = list(VERIFY_ROWS.get(h, (0, h // 2, h - 1)))
+    probes.sort(key=lambda r: abs(r - h // 2))
+    if oracle_rows is None:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_binding as ob
+
+        def oracle_rows(first, last):
+            p = base_params(m, cfg)
+            p.row_begin, p.row_end = first, last
+            return ob.render(sd, p, n_threads=cores)
+        if not cpu_msamples_per_s:                       # no cpu_baseline leg in this run (N > 1): a one-row, 4-spp probe of the oracle's rate
+            p = base_params(m, cfg)
+            p.spp, p.row_begin, p.row_end = min(4, cfg["spp"]), h // 2, h // 2 + 1
+            tp = time.perf_counter()
+            ob.render(sd, p, n_threads=1)
+            cpu_msamples_per_s = cores * w * p.spp / max(time.perf_counter() - tp, 1e-6) / 1e6
+        row_seconds = w * cfg["spp"] / (cpu_msamples_per_s / cores * 1e6)              # one row on one thread
+        if row_seconds > 3.0 * budget_seconds:           # e.g. config 5 at 4000 spp: ten minutes per row
+            return [{"row": None, "skipped": f"one oracle row of this workload takes ~{row_seconds:.0f} s on a host thread "
+                                             f"(budget {budget_seconds:.0f} s); the frame is verified at fewer samples by the N = 1 line and the GPU tests"}]
+        probes = probes[:max(1, int(budget_seconds / max(row_seconds, 1e-6)))]
     t0, out = time.perf_counter(), []
-    for r in VERIFY_ROWS.get(cfg["height"], (0, cfg["height"] // 2, cfg["height"] - 1)):
-        if time.perf_counter() - t0 > budget_seconds:
+    for r in probes:
+        if out and time.perf_counter() - t0 > budget_seconds:
             break
-        p = base_params(m, cfg)
-        p.row_begin, p.row_end = r, r + 1
-        want = ob.render(sd, p, n_threads=host_cores())
-        out.append({"row": r, "spp": cfg["spp"], "equal": bool(np.array_equal(frame_host[r:r + 1], want))})
+        first = max(0, min(r - band // 2, h - band))
+        want = oracle_rows(first, first + band)
+        got = frame_host[first:first + band]
+        rows_equal = [bool(np.array_equal(got[i], want[i])) for i in range(band)]
+        out.append({"row": r, "rows": [first, first + band], "spp": cfg["spp"], "equal": all(rows_equal),
+                    "rows_equal": sum(rows_equal)})
     return out
 
 
@@ -351,6 +480,15 @@ def launch_ranks(args, argv) -> int:
     """Start N fresh rank processes through torch.distributed.run and wait for them.  This process has not
     imported torch and never touches the GPU; the ranks are ordinary children (no exec of a GPU process)."""
     env = dict(os.environ)
+    if not args.dry_run:
+        # one rank per GPU: count the devices in a child (this process never imports torch) and refuse here, with one line,
+        # what RCCL would refuse inside init_process_group ("Duplicate GPU detected")
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], env=env, capture_output=True, text=True)
+        n = int(r.stdout.strip() or 0) if r.returncode == 0 and r.stdout.strip().isdigit() else 0
+        err = rank_device_error(args.gpus, n, False)
+        if err:
+            print(err[1], file=sys.stderr)
+            return err[0]
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -368,6 +506,8 @@ def parse_args(argv):
     ap.add_argument("--tile-rows", type=int, default=4)
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel (e.g. --config 5 --gpus 8 --spp 4000 = "
                                                         "BASELINE configs[4] in full); the workload string says so")
+    ap.add_argument("--size", default="", help="override the config's frame, WxH (e.g. --config parity --size 800x600 --spp 2 = the "
+                                               "reference's own operating point, main.rs:28 / mod.rs:605-613); the workload string says so")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank path on CPU (gloo, pattern renderer); measures nothing")
     return ap.parse_args(argv)
 
@@ -392,13 +532,13 @@ def main(argv=None) -> int:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     dry = args.dry_run
-    if not dry and not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the render path has no CPU fallback (use --dry-run to rehearse the rank plumbing)", file=sys.stderr)
-        return 3
+    err = rank_device_error(world, torch.cuda.device_count(), dry)       # before init_process_group, before the GPU is touched
+    if err:
+        if rank == 0:
+            print(err[1], file=sys.stderr)
+        return err[0]
     if not dry:
-        # one rank per GPU; with fewer GPUs than ranks (a rehearsal on a one-GPU box) the ranks share devices
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)                                 # one rank per GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
@@ -412,6 +552,11 @@ def main(argv=None) -> int:
     if args.spp > 0 and args.spp != cfg["spp"]:
         cfg["workload"] += f" [spp overridden: {args.spp} instead of {cfg['spp']}]"
         cfg["spp"] = args.spp
+    if args.size:
+        sw, sh = (int(v) for v in args.size.lower().split("x"))
+        if (sw, sh) != (cfg["width"], cfg["height"]):
+            cfg["workload"] += f" [frame overridden: {sw}x{sh} instead of {cfg['width']}x{cfg['height']}]"
+            cfg["width"], cfg["height"] = sw, sh
     if dry:                                               # small frame: the pattern renderer is numpy
         cfg.update(width=192, height=108, spp=1)
     w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
@@ -484,13 +629,34 @@ def main(argv=None) -> int:
                  + (" (overlapping the next frame's render)" if pipelined else ""))
     total_samples = w * h * spp
 
+    # N > 1: one gather + de-interleave on its own, after the clock has stopped (the timed region overlaps it with the next
+    # frame's render, so it cannot be read off the step time): rank 0's wall time of [gather, assemble], ranks released together
+    gather_ms = None
+    if world > 1:
+        reps, acc = 5, 0.0
+        for _ in range(reps):
+            barrier()
+            sync()
+            tg = time.perf_counter()
+            parts = m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
+            if rank == 0:
+                frame._assemble(parts, frame._stream())
+            sync()
+            acc += time.perf_counter() - tg
+        gather_ms = round(acc / reps * 1e3, 4)
+
     if dry:
         ok = True
         if rank == 0:
             import numpy as np
-            ok = bool(np.array_equal(frame.frame.numpy(), pattern_rows(range(h), w)))
+            got = frame.frame.numpy()
+            ok = bool(np.array_equal(got, pattern_rows(range(h), w)))
+            # the verification leg of a real N-rank run, with the pattern standing in for the oracle: same function, same fields
+            rows = verify_rows(m, None, cfg, got, oracle_rows=lambda first, last: pattern_rows(range(first, last), w))
+            ok = ok and all(r.get("equal") for r in rows)
             print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "frames_verified": ok, "launches_rank0": st["launches"], "backend": "gloo" if world > 1 else "none",
+                              "frames_verified": ok, "verified_rows": rows, "verified_frame": "gathered on rank 0" if world > 1 else "whole frame",
+                              "gather_ms": gather_ms, "launches_rank0": st["launches"], "backend": "gloo" if world > 1 else "none",
                               "kernel_ms_per_rank": kernel_ms_per_rank,
                               "config": {"workload": f"DRY RUN ({w}x{h} pattern frame, no GPU, nothing measured)", "partition": partition}}),
                   flush=True)
@@ -509,15 +675,24 @@ def main(argv=None) -> int:
     ctx.render_device(pc, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     work = ctx.stats()
+    counting_kernel = ctx.last_kernel()
+    flops = algorithmic_flops(work, mode=cfg["mode"], grid=uses_grid)      # of THIS rank's share
+    flops_all = flops
+    if world > 1:
+        t = torch.tensor([flops], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        flops_all = float(t.item())
 
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
-        flops = algorithmic_flops(work, mode=cfg["mode"], grid=uses_grid)
         traffic = profiled_traffic(kernel_name, cfg["workload"]) if world == 1 else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
         out_bytes = frame.rows * w * 4
-        in_bytes = 32 * len(sd.spheres) + 32 * len(sd.materials) + 96 + 12 * int(sd.texels.shape[0])
+        algo_bytes = algorithmic_bytes(sd, cfg["mode"], out_bytes)
         lane_slots = 64 * work["wave_iterations"]
+        # MIRT_FLAG_COUNT_WORK can force another schedule than the timed one (the pool's counting build, lane = sample instead
+        # of lane = pixel): the flop counts do not depend on the schedule, lane utilisation does
+        same_schedule = kernel_schedule(counting_kernel) == kernel_schedule(kernel_name)
         result = {
             "metric": "Msamples/sec (pixels x spp) at 1920x1080, 1000 spp" if args.config == "3" else "Msamples/sec (pixels x spp)",
             "value": round(value, 2),
@@ -543,6 +718,8 @@ def main(argv=None) -> int:
                 "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
                 "valu_busy_pct_profiled": (round(traffic[2], 1) if traffic and traffic[2] is not None else None),
                 "valu_lane_utilization_pct_profiled": (round(traffic[3], 1) if traffic and traffic[3] is not None else None),
+                "scope": "whole frame" if world == 1 else f"rank 0's share (its tiles: {frame.rows} of {h} rows); achieved_whole_job = all ranks' flops / slowest rank's kernel time",
+                "achieved_whole_job": round(flops_all / (kernel_ms_max * 1e-3) / 1e12, 3),
                 "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
@@ -551,11 +728,13 @@ def main(argv=None) -> int:
                 "flop_per_sample": round(flops / max(1, work["samples"]), 2),
                 "grays_per_s": round(work["rays"] / (kernel_ms * 1e-3) / 1e9, 3),
                 "gtests_per_s": round(work["sphere_tests"] / (kernel_ms * 1e-3) / 1e9, 3),
-                "lane_utilization": round(work["lane_iterations"] / lane_slots, 4) if lane_slots else None,
+                "counting_kernel": counting_kernel,
+                "lane_utilization": round(work["lane_iterations"] / lane_slots, 4) if lane_slots and same_schedule else None,
+                "lane_utilization_note": None if same_schedule else "the counting launch ran another schedule than the timed kernel: not reported",
                 "grid_walk_lane_utilization": (round(work["grid_cells"] / (64 * work["grid_wave_cells"]), 4)
-                                               if work.get("grid_wave_cells") else None),
-                "hbm": {"algorithmic_bytes_per_launch": out_bytes + in_bytes,
-                        "achieved_gbs": round((out_bytes + in_bytes) / (kernel_ms * 1e-3) / 1e9, 4),
+                                               if work.get("grid_wave_cells") and same_schedule else None),
+                "hbm": {"algorithmic_bytes_per_launch": algo_bytes,
+                        "achieved_gbs": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 4),
                         "peak_gbs": PEAK_HBM_GBS},
                 "note": "fp32 vector-ALU roofline (no MFMA on this path; HBM traffic is the framebuffer + the scene tables once); "
                         "rocprofv3 summaries under profiles/",
@@ -565,14 +744,26 @@ def main(argv=None) -> int:
             result["fast_math"] = fast_math_line(m, torch, ctx, base, frame.frame, total_samples, flops)
             if args.config == "4":
                 result["texel_tiles"] = texel_tiles_line(m, torch, ctx, base, frame.frame, total_samples)
+            if args.config == "2":
+                result["steady_state"] = steady_state_line(m, torch, ctx, base, w, h)
+        if world == 1 and cfg["mode"] == "parity":
+            result["parity_schedules"] = parity_schedules_line(m, torch, ctx, base, w, h)
+        if world > 1:
+            result["gather_ms"] = gather_ms
+            result["gather_note"] = "one gather + de-interleave alone on rank 0 (no render), after the timed region; the timed steps overlap it with the next frame's render"
+        cpu_rate = None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, sd, cfg)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+            cpu_rate = result["cpu_baseline"]["value"] if cfg["mode"] == "pt" else None
             if cfg["mode"] == "pt":                          # the reference's own CPU loop beside it (north_star's last sentence)
                 sys.path.insert(0, str(ROOT / "tests"))
                 import oracle_binding as ob
                 result["cpu_baseline"]["layer_rs"] = layer_rs_baseline(m, ob, build_scene(m, CONFIGS["parity"]), 1920, 1080)
-            result["verified_rows"] = verify_rows(m, sd, cfg, frame.frame.cpu().numpy())
+        if not args.no_cpu_baseline:
+            # the frame the timed region left on rank 0 -- for N > 1 the one gathered over RCCL -- against oracle rows
+            result["verified_rows"] = verify_rows(m, sd, cfg, frame.frame.cpu().numpy(), cpu_msamples_per_s=cpu_rate)
+            result["verified_frame"] = "whole frame" if world == 1 else f"gathered from {world} ranks on rank 0"
         print(json.dumps(result), flush=True)
 
     ctx.close()

@@ -86,6 +86,11 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     d = json.loads(lines[0])
     assert d["dry_run"] and d["n_gpus"] == 2 and d["frames_verified"] and d["launches_rank0"] == 3
     assert len(d["kernel_ms_per_rank"]) == 2 and "2 ranks + 1 gather per frame" in d["config"]["partition"]
+    # the verification leg of a real N-rank line: bands of rows of the frame GATHERED on rank 0 against the checker (here the
+    # pattern), and the stand-alone gather + assemble time
+    assert d["verified_frame"] == "gathered on rank 0"
+    assert len(d["verified_rows"]) >= 3 and all(r["equal"] and r["rows_equal"] == r["rows"][1] - r["rows"][0] for r in d["verified_rows"])
+    assert d["gather_ms"] is not None and d["gather_ms"] > 0.0
 
 
 def test_bench_rejects_a_world_size_mismatch():
@@ -95,3 +100,46 @@ def test_bench_rejects_a_world_size_mismatch():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True,
                        timeout=300, cwd="/tmp")
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_one_rank_per_gpu_is_checked_before_the_process_group():
+    """RCCL refuses two ranks on one device inside init_process_group ("Duplicate GPU detected"): bench.py says so itself, in
+    one line, with exit code 2 -- in the launcher and again in every rank -- and 3 when there is no GPU at all."""
+    assert bench.rank_device_error(2, 1, False)[0] == 2 and "2 GPUs, 1 visible" in bench.rank_device_error(2, 1, False)[1]
+    assert bench.rank_device_error(8, 4, False)[0] == 2
+    assert bench.rank_device_error(1, 0, False)[0] == 3 and bench.rank_device_error(2, 0, False)[0] == 3
+    assert bench.rank_device_error(1, 1, False) is None and bench.rank_device_error(8, 8, False) is None
+    assert bench.rank_device_error(2, 0, True) is None                     # --dry-run needs no GPU
+    import subprocess
+    # a bare `--gpus 2` on this GPU-less machine: refused by the launcher, nothing is spawned
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=_bare_env(), capture_output=True, text=True, timeout=300, cwd="/tmp")
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.returncode == 3 and "no GPU visible" in r.stderr and "Traceback" not in r.stderr
+    # ... and as a rank of a 2-rank job (what the driver's torch.distributed.run starts), before init_process_group
+    env = dict(_bare_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode in (2, 3) and "Traceback" not in r.stderr and r.stdout.strip() == ""
+
+
+def test_algorithmic_bytes_count_only_what_a_launch_reads():
+    """config 3 = framebuffer + camera + 3 spheres + 5 materials = 8 294 752 B -- not the texel table, which that
+    scene never reads; config 4 adds the 1024 x 512 earth texture once; parity mode two texels."""
+    import weekend_raytracer_wgpu_amd as m
+
+    def sd_of(name, w=1920, h=1080):
+        return bench.build_scene(m, dict(bench.CONFIGS[name]))
+    fb = 1920 * 1080 * 4
+    sd3 = sd_of("3")
+    assert bench.algorithmic_bytes(sd3, "pt", fb) == 8294752
+    sd4 = sd_of("4")
+    assert bench.algorithmic_bytes(sd4, "pt", fb) == fb + 96 + 32 * len(sd4.spheres) + 32 * len(sd4.materials) + 12 * 1024 * 512
+    sdp = sd_of("parity")
+    assert bench.algorithmic_bytes(sdp, "parity", fb) == fb + 96 + 32 * 6 + 32 * 5 + 24
+
+
+def test_kernel_schedule_names():
+    assert bench.kernel_schedule("render_pt_strip_kernel<false,false,false,true>") == "strip/pixel"
+    assert bench.kernel_schedule("render_pt_strip_kernel<true,false,false,false>") == "strip/sample"
+    assert bench.kernel_schedule("render_pt_pool_kernel<256,112,6,false,false,3,false>") == bench.kernel_schedule("render_pt_pool_kernel<256,112,1,true,false,5,false>") == "pool"
+    assert bench.kernel_schedule("render_parity_kernel<false,true>") == "parity/pixel" != bench.kernel_schedule("render_parity_kernel<true,false>")

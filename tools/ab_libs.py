@@ -3,12 +3,16 @@
 §5.4 rule 24): kernel time from the library's own HIP events, images compared with the first build's.
 
     python tools/ab_libs.py [--scene three_spheres] [--size 1920x1080] [--spp 1000] [--rounds 5] [--flags 0]
-                            [--allow-diff] lib_a.so lib_b.so ...
+                            [--allow-diff] lib_a.so lib_b.so lib_b.so@MIRT_PINHOLE=0 ...
+
+`lib.so@NAME=VALUE[,NAME=VALUE]` creates that build's context with the tuning variables set (they are read once, in
+mirt_ctx_create), so one build can appear several times with different knobs.
 
 Builds are usually produced with `make -C weekend-raytracer-wgpu_amd/csrc OUT=../../tools/_scratch/libs/libmirt_x.so EXTRA=-D...`.
 """
 import argparse
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
@@ -35,14 +39,25 @@ sd = layer_scene_data(w, h) if a.scene == "layer_scene" else scene_data(a.scene,
 p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT if a.mode == "pt" else m.MIRT_MODE_PARITY, num_bounces=8, flags=a.flags)
 
 libs = []
-for path in a.libs:
+for spec in a.libs:
+    path, _, envs = spec.partition("@")
     lib = C.CDLL(str(Path(path).resolve()))
     _abi.bind(lib)
     ctx = C.c_void_p()
-    assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
+    knobs = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     sc = sd.as_c()
     assert lib.mirt_ctx_set_scene(ctx, C.byref(sc)) == 0, lib.mirt_last_error()
-    libs.append((Path(path).name, lib, ctx))
+    libs.append((Path(path).name + ("@" + envs if envs else ""), lib, ctx))
 
 
 def render(lib, ctx):
@@ -74,6 +89,6 @@ base = np.median(times[libs[0][0]])
 for name, lib, ctx in libs:
     ts = times[name]
     kn = lib.mirt_ctx_last_kernel(ctx).decode()
-    print(f"{name:28s} median {np.median(ts):8.3f} ms  min {np.min(ts):8.3f} ms  {100 * np.median(ts) / base:6.1f} %  "
+    print(f"{name:40s} median {np.median(ts):8.3f} ms  min {np.min(ts):8.3f} ms  {100 * np.median(ts) / base:6.1f} %  "
           f"-> {w * h * a.spp / np.median(ts) / 1e3:9.1f} Msamples/s   {kn}")
     lib.mirt_ctx_destroy(ctx)

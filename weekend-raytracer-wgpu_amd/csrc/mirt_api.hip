@@ -120,7 +120,10 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
         }
     }
     if (small.size() < mirt::kGridMinSpheres / 2 || big.size() > 64) return blob;
-    const double cell_factor = cell_factor_knob > 0.0 ? cell_factor_knob : 4.0;   // cell = 4 median radii: a binned sphere spans at most 3 cells per axis
+    // cell = 2.5 median radii (a binned sphere of up to 4 median radii spans at most 5 cells per axis).  Measured on RTIOW, 1080p x 128 spp,
+    // records stored once per sphere: 4 -> 14.31 ms, 3.5 -> 13.95, 3 -> 13.35, 2.75 -> 13.38, 2.5 -> 13.18, 2.25 -> 13.11, 2 -> 19.7 (the cell
+    // table outgrows LDS: 128-slot pools); fewer tests per ray against more cells per ray (profiles/r03_c5_cell_size.txt)
+    const double cell_factor = cell_factor_knob > 0.0 ? cell_factor_knob : 2.5;   // mirt_ctx_set_scene passes the factor it settles on
     double cell = cell_factor * r_med;
     uint32_t dims[3];
     for (;;) {
@@ -157,18 +160,20 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     h.n_big = (uint32_t)big.size();
     const size_t hdr_u16 = sizeof(mirt::GridHeader) / 2;
     h.off_big = (uint32_t)hdr_u16;
-    h.off_start = h.off_big + (uint32_t)big.size();
-    h.off_items = h.off_start + ncells + 1;
+    h.off_items = h.off_big + (uint32_t)big.size();
     size_t bytes = ((size_t)h.off_items + n_items) * 2;
     h.off_ops = (uint32_t)bytes;                                  // u8 per sphere, filled by the caller (needs the materials)
-    bytes = (bytes + n + 15) & ~size_t(15);
+    bytes = (bytes + n + 3) & ~size_t(3);
+    h.off_cells = (uint32_t)bytes;                                // u32 per cell: first item | count << 16
+    bytes = (bytes + 4 * ((size_t)ncells + 1) + 15) & ~size_t(15);     // + one entry: `first` of the end of the list
     h.off_big_recs = (uint32_t)bytes;
     bytes += big.size() * 16;
-    h.off_item_recs = (uint32_t)bytes;
-    bytes += n_items * 16;
+    h.off_recs = (uint32_t)bytes;
+    bytes += (size_t)n * 16;                                      // one record per SPHERE, indexed by sphere id
     h.total_bytes = (uint32_t)bytes;
     blob.assign(h.total_bytes, 0);
     uint16_t* u = reinterpret_cast<uint16_t*>(blob.data());
+    uint32_t* cells = reinterpret_cast<uint32_t*>(blob.data() + h.off_cells);
     std::memcpy(blob.data(), &h, sizeof h);
     // test record of sphere i: centre and r*r, the first half of its PreparedSphere (same IEEE product as set_scene's)
     auto put_rec = [&](size_t byte_off, uint16_t i) {
@@ -178,10 +183,11 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     for (size_t i = 0; i < big.size(); ++i) { u[h.off_big + i] = big[i]; put_rec(h.off_big_recs + 16 * i, big[i]); }
     uint32_t pos = 0;
     for (uint32_t c = 0; c < ncells; ++c) {
-        u[h.off_start + c] = (uint16_t)pos;
-        for (uint16_t id : lists[c]) { put_rec(h.off_item_recs + 16 * (size_t)pos, id); u[h.off_items + pos++] = id; }
+        cells[c] = pos | ((uint32_t)lists[c].size() << 16);       // n_items <= 65535, so both halves fit
+        for (uint16_t id : lists[c]) u[h.off_items + pos++] = id;
     }
-    u[h.off_start + ncells] = (uint16_t)pos;
+    for (uint32_t i = 0; i < n; ++i) put_rec(h.off_recs + 16 * (size_t)i, (uint16_t)i);
+    cells[ncells] = pos;
     return blob;
 }
 
@@ -276,7 +282,10 @@ struct MirtContext {
     size_t cap_pmats = 0;
     unsigned char* d_grid = nullptr;        // uniform grid blob (many-sphere scenes), see build_grid
     size_t cap_grid = 0;
+    mirt::ShadeRec* d_shade = nullptr;      // [n_spheres] shading records of the grid builds (sphere + its material in one line)
+    size_t cap_shade = 0;
     uint32_t grid_bytes = 0;
+    bool     have_shade = false;             // d_shade holds this scene's records
     bool     grid_packable = false;          // every grid dimension <= 1024: a cell fits the pool kernel's packed cell word
     bool     fits_flat = true;               // spheres + materials fit the LDS budget (flat kernels usable)
     float*                d_texels = nullptr;
@@ -462,7 +471,7 @@ void mirt_ctx_destroy(MirtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_texels);
+    (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_shade); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
@@ -480,7 +489,17 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     // The flat kernels stage spheres AND materials in LDS; the grid build (path-traced mode, many spheres)
     // only the spheres + the grid.  A scene is accepted if at least one of the two layouts fits.
     const bool fits_flat = kx::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
-    std::vector<unsigned char> grid = build_grid(s->spheres, s->n_spheres, c->tuning.grid_cell, c->tuning.grid_big);
+    // The cell size trades sphere tests against cells walked AND against LDS: the blob shares the CU's 160 KB with the path pools,
+    // and a pool geometry lost to a large cell table costs more than finer cells bring (RTIOW: cell = 2 median radii drops the
+    // pools from 152 to 128 slots per wave and the frame from 13.2 to 19.7 ms).  So: the default cell, and coarser ones (x 1.26 per
+    // step, up to the 4 median radii of round 2) only while the blob would not leave the pooled kernel its 152-slot geometry.
+    std::vector<unsigned char> grid;
+    for (double f = c->tuning.grid_cell > 0.0 ? c->tuning.grid_cell : 2.5;; f *= 1.26) {
+        grid = build_grid(s->spheres, s->n_spheres, f, c->tuning.grid_big);
+        if (grid.empty() || c->tuning.grid_cell > 0.0 || f >= 4.0) break;
+        const size_t beside = kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size();
+        if (beside < c->lds_per_block && kx::pool_config_grid(c->lds_per_block - beside).slots >= 152u) break;
+    }
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
                            kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;   // camera (+ sky) + the blob
     if (!fits_flat && !fits_grid)
@@ -563,7 +582,17 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
         for (uint32_t i = 0; i < s->n_spheres; ++i) grid[gh->off_ops + i] = (unsigned char)prep[i].op;
     }
+    // grid builds: sphere centre, 1/r and a copy of the sphere's material in one 64-byte record (mirt_kernels.h: ShadeRec)
+    std::vector<mirt::ShadeRec> shade;
+    if (fits_grid && s->n_materials) {
+        shade.resize(s->n_spheres);
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            const uint32_t mi = prep[i].material_idx < s->n_materials ? prep[i].material_idx : 0u;   // out of range: pt_scene_status refuses the launch
+            shade[i] = mirt::ShadeRec{ prep[i].cx, prep[i].cy, prep[i].cz, prep[i].inv_r, pmats[mi] };
+        }
+    }
     int rc;
+    if (!shade.empty() && (rc = ensure_capacity(&c->d_shade, &c->cap_shade, shade.size())) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_pmats, &c->cap_pmats, (size_t)s->n_materials)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_spheres, &c->cap_spheres, (size_t)s->n_spheres)) != MIRT_OK) return rc;
     if ((rc = ensure_capacity(&c->d_mats, &c->cap_mats, (size_t)s->n_materials)) != MIRT_OK) return rc;
@@ -574,6 +603,8 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_mats, s->materials, (size_t)s->n_materials * sizeof(MirtMaterial), hipMemcpyHostToDevice));
     if (s->n_materials) HIP_TRY(hipMemcpy(c->d_pmats, pmats.data(), pmats.size() * sizeof(mirt::PreparedMaterial), hipMemcpyHostToDevice));
     if (s->n_texels) HIP_TRY(hipMemcpy(c->d_texels, s->texels, (size_t)s->n_texels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    if (!shade.empty()) HIP_TRY(hipMemcpy(c->d_shade, shade.data(), shade.size() * sizeof(mirt::ShadeRec), hipMemcpyHostToDevice));
+    c->have_shade = !shade.empty();
     {
         c->grid_bytes = fits_grid ? (uint32_t)grid.size() : 0u;
         c->grid_packable = false;
@@ -697,7 +728,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // the largest geometry only)
     const size_t lds_beside = scene_lds_g + c->grid_bytes;
     mirt::PoolConfig pcg = kx::pool_config_grid((size_t)c->lds_per_block > lds_beside ? (size_t)c->lds_per_block - lds_beside : 0);
-    if (count && pcg.slots != mirt::kGridPoolSlotChoices[0]) pcg.slots = 0;
+    if (count && pcg.slots != mirt::kGridPoolSlotChoices[0] && pcg.slots != mirt::kGridPoolSlotChoices[1]) pcg.slots = 0;
     const size_t lds_pool_grid_block = lds_beside + pcg.lds_bytes;
     const uint32_t pool_grid_waves_per_cu = pcg.slots ? (uint32_t)(c->lds_per_cu / lds_pool_grid_block) * (pcg.threads / 64u) : 0u;
     bool pool_grid = grid_ok && c->grid_packable && pcg.slots != 0 && tune.pool_config < 0 && p->num_bounces <= 255u &&
@@ -767,6 +798,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block);
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
+    a.shade = (use_grid && c->have_shade) ? c->d_shade : nullptr;
     a.grid_pool_slots = pool_grid ? pcg.slots : 0u;
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
@@ -784,7 +816,10 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.static_units = 0;
     if (by_pixel) {
         a.n_units = (uint32_t)((npix + 63u) / 64u);
-        a.static_units = (pt && p->spp < 8u) ? 1u : 0u;   // measured crossover (tools/low_spp.py); the parity kernel always dispenses
+        // units dealt round-robin instead of dispensed: path-traced mode below 8 spp (measured crossover, tools/low_spp.py); parity mode
+        // always -- its lane = pixel units are a few dozen sphere tests each, and one dispenser atomic per unit (14 ns, serialised on
+        // its address) was the whole kernel time: 7 500 units of an 800x600 frame at 2 spp 94 us whatever the work
+        a.static_units = (!pt || p->spp < 8u) ? 1u : 0u;
     }
 
     uint32_t blocks;
@@ -816,6 +851,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
     const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
+#ifdef MIRT_DIAG_STAMPS
+    HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
+#endif
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
     HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
     // the opt-in fast-math build of the path-traced kernels; counting launches always run the exact build
@@ -897,6 +935,14 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
     c->stats.launches = c->launches_folded;
     c->ms_folded = 0.0;
     c->launches_folded = 0;
+#ifdef MIRT_DIAG_STAMPS
+    if (had_launch) {                            // wave-cycles per section of the pooled kernel (mirt_kernels.hip: Stamps)
+        unsigned long long h[mirt::kNumCounters];
+        HIP_TRY(hipMemcpy(h, c->d_counters + c->last_slot * mirt::kNumCounters, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "MIRT_STAMPS pop %llu gen %llu scatter %llu big %llu setup_fresh %llu cells_fresh %llu tail %llu setup_resume %llu cells_resume %llu strip_end %llu\n",
+                h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27]);
+    }
+#endif
     if (had_launch && c->stats_counted) {
         unsigned long long h[mirt::kNumCounters];
         HIP_TRY(hipMemcpy(h, c->d_counters + c->last_slot * mirt::kNumCounters, sizeof h, hipMemcpyDeviceToHost));
@@ -915,6 +961,10 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.texel_fetches[1] = h[mirt::kCntTexelsLater];
         c->stats.texel_tile_hits[0] = h[mirt::kCntTileHitsPrimary];
         c->stats.texel_tile_hits[1] = h[mirt::kCntTileHitsLater];
+#ifdef MIRT_DIAG_STEPS
+        fprintf(stderr, "MIRT_DIAG steps scatter/gen/walk %llu %llu %llu paths %llu %llu %llu ff_steps %llu traces cut/hit/miss %llu %llu %llu\n",
+                h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27]);
+#endif
 #ifdef MIRT_PROBE_TEXELS
         c->stats.grid_cells = h[12]; c->stats.grid_wave_cells = h[13]; c->stats.lane_iterations = h[14]; c->stats.wave_iterations = h[15];
 #endif

@@ -36,17 +36,29 @@ struct PreparedMaterial {
 };
 static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
 
+// Many-sphere scenes (grid builds): what shading a hit on sphere i needs, in ONE 64-byte line of global memory / L2 --
+// the sphere's centre and 1/r and a copy of its material -- so that the scatter step issues four independent 16-byte
+// loads instead of sphere -> material_idx -> material (two dependent round trips of 200+ cycles each at 4 waves per SIMD).
+struct ShadeRec {
+    float            cx, cy, cz, inv_r;
+    PreparedMaterial m;
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec is one 64-byte line");
+
 // Uniform grid over the small spheres of a many-sphere scene (>= kGridMinSpheres): the nearest-hit scan
 // visits only the cells a ray crosses (3D-DDA) plus a short list of "big" spheres.  The grid is
 // CONSERVATIVE (every sphere is listed in all cells its slightly enlarged bounding box touches) and the
 // hit rule breaks ties by sphere index, so the result is identical to the reference's flat scan.
 // Layout of the blob (all of it is staged into LDS; the kernels of a grid build read NO other sphere data from LDS):
-//   GridHeader | big ids [n_big] u16 | cell starts [ncells + 1] u16 | item ids [n_items] u16 (ascending within a cell)
+//   GridHeader | big ids [n_big] u16 | item ids [n_items] u16 (ascending within a cell)
 //   | routine queue of every sphere [n_spheres] u8 (PreparedSphere.op)
-//   | 16-byte aligned: test records {cx, cy, cz, r^2} of the big spheres [n_big] | of the items [n_items], in list order.
-// The records are COPIES of the first half of the spheres' PreparedSphere (a sphere listed in k cells is stored k
-// times): a test then needs ONE LDS round trip (record + id, independent addresses) instead of two dependent ones
-// (id, then the sphere), which is what bounds the walk (4 waves per SIMD, LDS-latency-bound).
+//   | 4-byte aligned: cell table [ncells + 1] u32 = first item | item count << 16 (one LDS read per cell)
+//   | 16-byte aligned: test records {cx, cy, cz, r^2} of the big spheres [n_big], in list order (a COPY: the always-tested list
+//     needs no id -> record indirection) | of EVERY sphere [n_spheres], by sphere id.
+// A record is the first half of the sphere's PreparedSphere.  A cell's item test reads the id, then the record: two dependent
+// LDS reads.  (Round 2 stored a record per list ENTRY -- one round trip, but a sphere listed in k cells stored k times, 17 KB for
+// RTIOW; stored once per sphere the blob is 8 KB smaller, the pools grow by 8 slots per wave, and -- what pays -- the cells can
+// be made smaller without the blob outgrowing LDS: cell = 2.5 median radii instead of 4, -9 % on RTIOW.)
 struct GridHeader {
     float    org[3];        // lower corner
     float    cell[3];       // cell size per axis
@@ -54,12 +66,12 @@ struct GridHeader {
     uint32_t dims[3];
     uint32_t n_big;         // spheres tested for every ray (too large for the grid)
     uint32_t off_big;       // offsets in uint16 units from the start of the blob
-    uint32_t off_start;     // [ncells + 1] first item of each cell
+    uint32_t off_cells;     // BYTE offset (multiple of 4) of the cell table
     uint32_t off_items;     // sphere ids, ascending within a cell
     uint32_t total_bytes;   // multiple of 16
     uint32_t off_ops;       // BYTE offset of the per-sphere routine-queue table
-    uint32_t off_big_recs;  // BYTE offsets (multiples of 16) of the test records
-    uint32_t off_item_recs;
+    uint32_t off_big_recs;  // BYTE offsets (multiples of 16) of the test records: the big spheres' copies ...
+    uint32_t off_recs;      // ... and every sphere's, by id
 };
 static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte copies");
 constexpr uint32_t kGridMinSpheres = 32;
@@ -68,7 +80,11 @@ constexpr uint32_t kGridMaxCells   = 8192;
 constexpr uint32_t kStripLevels   = 5;    // strip widths 16, 8, 4, 2, 1
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
+#if defined(MIRT_DIAG_STEPS) || defined(MIRT_DIAG_STAMPS)   // diagnosis builds (tools/step_stats.py): ten more counters, printed by mirt_ctx_get_stats
+constexpr uint32_t kNumCounters   = 28;
+#else
 constexpr uint32_t kNumCounters   = 18;   // u64 work counters (MirtStats order)
+#endif
 constexpr uint32_t kMaxLdsBytes   = 120 * 1024; // scene budget in LDS (of 160 KB per CU); sphere ids are 12 bit in the pool kernel
 
 // pooled path-traced kernel: every wave keeps a pool of paths in LDS, queued by pending shading routine
@@ -85,7 +101,7 @@ constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many sampl
 // 512 threads x 112 slots, two blocks 17.3 ms; x 128 slots 16.6; 1024 x 144 15.9; 1024 x 152 15.7; one 512-thread
 // block per CU (8 waves) with 160-256 slots 26.3 -- the pools want to be as large as 16 resident waves allow.
 constexpr uint32_t kGridPoolThreads = 1024;
-constexpr uint32_t kGridPoolSlotChoices[3] = { 152, 128, 96 };   // the largest geometry whose block fits LDS is taken
+constexpr uint32_t kGridPoolSlotChoices[4] = { 160, 152, 128, 96 };   // the largest geometry whose block fits LDS is taken
 // Samples per pixel from which the pooled kernel is the default (below: the strip kernel, lane = pixel).  A 16-pixel strip
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
@@ -120,6 +136,7 @@ struct RenderArgs {
     uint32_t*               out;           // compact RGBA8, one u32 per pixel
     unsigned long long*     counters;      // [kNumCounters] of THIS launch (one block per event slot), COUNT builds only
     const unsigned char*    grid;          // nullable: GridHeader + lists (strip kernel, GRID build)
+    const ShadeRec*         shade;         // grid builds: [n_spheres] shading records (nullable otherwise)
     uint32_t                grid_bytes;
     uint32_t                grid_pool_slots;   // pool kernel, grid build: slots per wave of the geometry chosen on the host
     uint32_t*               work_counter;  // dynamic work dispenser: THIS launch's own word (one per event slot), preset before the launch

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
     Work<COUNT> work;
     work.clear();
 
-    for (uint32_t strip = first_unit(); strip < A.n_units; strip = next_unit(A, lane)) {
+    const uint32_t grid_waves = gridDim.x * (kBlockThreads / 64u);
+    for (uint32_t strip = first_unit(); strip < A.n_units; strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit(A, lane)) {
         if constexpr (BY_PIXEL) {
             const uint32_t pi = strip * 64u + lane;
             const bool inside = pi < npix;
@@ -540,7 +541,8 @@ struct Rng {
 // camera constants hoisted into registers once per thread
 struct CamRegs {
     f3 eye, hor, ver, llc;
-    const float* cam;          // LDS: lens basis and radius are read where a thin lens needs them
+    f3 cam_u, cam_v;           // lens basis and radius: loaded only for cameras with a lens
+    float lens_radius;
     bool pinhole;              // wave-uniform: the lens offset is exactly zero for every draw (see generate_primary)
     float inv_w, inv_h;
 };
@@ -555,9 +557,11 @@ MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
     c.ver = mk(S.cam[8], S.cam[9], S.cam[10]);
     c.llc = mk(S.cam[20], S.cam[21], S.cam[22]);
     // RenderArgs.cam._padding5 is written by the host for every launch (launch_render): 1 = pinhole.  All lanes read the
-    // same LDS word; readfirstlane tells the compiler so.
+    // same LDS word; readfirstlane tells the compiler so.  (All six reads are issued together, lens or not: one LDS round trip.)
+    c.cam_u = mk(S.cam[12], S.cam[13], S.cam[14]);
+    c.cam_v = mk(S.cam[16], S.cam[17], S.cam[18]);
+    c.lens_radius = S.cam[19];
     c.pinhole = __builtin_amdgcn_readfirstlane(bits(S.cam[23])) != 0u;
-    c.cam = S.cam;
     c.inv_w = 1.0f / (float)A.width;
     c.inv_h = 1.0f / (float)A.height;
     return c;
@@ -587,14 +591,11 @@ MIRT_DEV void generate_primary(const RenderArgs& A, const CamRegs& C, uint32_t x
         rng.skip();
         ro = C.eye;
     } else {
-        const f3 cam_u = mk(C.cam[12], C.cam[13], C.cam[14]);
-        const f3 cam_v = mk(C.cam[16], C.cam[17], C.cam[18]);
-        const float lens_radius = C.cam[19];
         const float lr = sqrt_unit(rng.next());
         const SinCos la = sincos_small(rng.next_scaled(kTwoPi * 0x1p-32f));
-        const float lpx = lens_radius * (lr * la.c);
-        const float lpy = lens_radius * (lr * la.s);
-        ro = C.eye + fma3(lpy, cam_v, lpx * cam_u);
+        const float lpx = C.lens_radius * (lr * la.c);
+        const float lpy = C.lens_radius * (lr * la.s);
+        ro = C.eye + fma3(lpy, C.cam_v, lpx * C.cam_u);
     }
     rd = fma3(v, C.ver, fma3(u, C.hor, C.llc)) - ro;
 }
@@ -670,6 +671,42 @@ MIRT_DEV int nearest_hit(const SceneLds& S, uint32_t n_spheres, f3 ro, f3 rd, bo
 
 MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
 
+// pool kernel, grid builds: cells a path may visit in the step that starts its walk / in an OP_WALK step that resumes it
+#ifndef MIRT_WALK_FRESH
+#define MIRT_WALK_FRESH 3
+#endif
+#ifndef MIRT_WALK_RESUME
+#define MIRT_WALK_RESUME 3
+#endif
+constexpr uint32_t kWalkCellsFresh = MIRT_WALK_FRESH, kWalkCellsResume = MIRT_WALK_RESUME;
+
+// In-kernel timing of the pooled kernel's sections (diagnosis builds only, -DMIRT_DIAG_STAMPS; tools/step_stats.py): s_memtime at
+// the section boundaries, summed per wave and added to the launch's counters 18.. at the end of every strip.
+#ifdef MIRT_DIAG_STAMPS
+struct Stamps {
+    unsigned long long acc[10];
+    unsigned long long prev;
+    MIRT_DEV void start()
+    {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = 0;
+        prev = __builtin_amdgcn_s_memtime();
+    }
+    MIRT_DEV void mark(int i) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc[i] += t - prev; prev = t; }
+    MIRT_DEV void flush(unsigned long long* g, uint32_t lane)
+    {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { if (lane == 0) atomicAdd(&g[18 + i], acc[i]); acc[i] = 0; }
+    }
+};
+#else
+struct Stamps {
+    MIRT_DEV void start() {}
+    MIRT_DEV void mark(int) {}
+    MIRT_DEV void flush(unsigned long long*, uint32_t) {}
+};
+#endif
+
 // ---- nearest hit through the uniform grid (many-sphere scenes) ----
 //
 // Equivalence with the flat scan (nearest_hit above).  For one sphere let f = its first root above
@@ -683,11 +720,11 @@ MIRT_DEV float max_(float a, float b) { return (b > a) ? b : a; }
 struct GridLds {
     const GridHeader*     h;
     const unsigned short* big;        // ids of the big spheres
-    const unsigned short* start;
+    const uint32_t*       cells;      // per cell: first item | item count << 16
     const unsigned short* items;      // ids of the cells' items
     const unsigned char*  ops;        // routine queue of every sphere (PreparedSphere.op)
     const float4*         big_recs;   // {centre, r^2} of the big spheres, in list order
-    const float4*         item_recs;  // ... of the items, in list order
+    const float4*         recs;       // ... of every sphere, by sphere id (the cells' items are ids)
 };
 
 // one sphere test from its record s4 = {centre, r^2} (a copy of the first half of PreparedSphere i)
@@ -726,11 +763,11 @@ MIRT_DEV GridLds stage_grid(const RenderArgs& A, unsigned char* gdst)
     G.h = reinterpret_cast<const GridHeader*>(gdst);
     const unsigned short* base = reinterpret_cast<const unsigned short*>(gdst);
     G.big = base + G.h->off_big;
-    G.start = base + G.h->off_start;
+    G.cells = reinterpret_cast<const uint32_t*>(gdst + G.h->off_cells);
     G.items = base + G.h->off_items;
     G.ops = gdst + G.h->off_ops;
     G.big_recs = reinterpret_cast<const float4*>(gdst + G.h->off_big_recs);
-    G.item_recs = reinterpret_cast<const float4*>(gdst + G.h->off_item_recs);
+    G.recs = reinterpret_cast<const float4*>(gdst + G.h->off_recs);
     return G;
 }
 
@@ -759,8 +796,8 @@ MIRT_DEV void test_cell_items(const GridLds& G, uint32_t first, uint32_t count, 
     for (uint32_t n = 0; ballot_(n < count); n += 2) {
         const bool on0 = n < count, on1 = n + 1 < count;
         const uint32_t k0 = on0 ? first + n : 0u, k1 = on1 ? first + n + 1 : 0u;
-        const float4 r0 = G.item_recs[k0], r1 = G.item_recs[k1];
         const uint32_t i0 = G.items[k0], i1 = G.items[k1];
+        const float4 r0 = G.recs[i0], r1 = G.recs[i1];                    // records by sphere id
         test_sphere<COUNT>(r0, i0, ro, rd, a, inv_a, on0, closest, best, work);
         if (ballot_(on1)) test_sphere<COUNT>(r1, i1, ro, rd, a, inv_a, on1, closest, best, work);
     }
@@ -822,8 +859,9 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
         if (walking) {
             const uint32_t c = (uint32_t)((cz * dy + cy) * dx + cx);
-            first = G.start[c];
-            count = (uint32_t)G.start[c + 1] - first;
+            const uint32_t cw = G.cells[c];
+            first = cw & 0xffffu;
+            count = cw >> 16;
         }
         test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
         {   // one DDA step, branch-free (see grid_walk)
@@ -854,7 +892,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 
 template <bool COUNT>
 MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool active, bool resume /* wave-uniform */, uint32_t budget,
-                        float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane)
+                        float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane, Stamps& stamps)
 {
     const float a = dot(rd, rd);
     const float inv_a = rcp_(a);
@@ -891,7 +929,9 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         closest = kMaxT;
         best = -1;
         if (active) work.add(kCntRays);
+        stamps.mark(4);                                       // (diagnosis builds) the clip against the grid's box
         test_big_spheres<COUNT>(G, ro, rd, a, inv_a, active, closest, best, work);
+        stamps.mark(3);
         walking = inside && (tmin <= tmax) && (tmin < closest);
         const f3 inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
         const f3 p0 = fma3(tmin, rd, ro);
@@ -912,13 +952,17 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
     const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
     const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
 
+    if (resume) stamps.mark(7); else stamps.mark(4);
+    // (Letting an instalment run past its budget while most lanes are still walking was measured: the fuller instalments gain 1-2 %,
+    //  but the loop header it needs -- ballot, population count and two compares instead of `it < budget && any` -- costs this loop 5 %.)
     for (uint32_t it = 0; it < budget && ballot_(walking); ++it) {
         uint32_t first = 0, count = 0;
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
         {   // no exec-mask region: lanes that are not walking read cell 0 and take no items
             const uint32_t c = walking ? (uint32_t)((cz * dy + cy) * dx + cx) : 0u;
-            first = G.start[c];
-            count = walking ? (uint32_t)G.start[c + 1] - first : 0u;
+            const uint32_t cw = G.cells[c];
+            first = cw & 0xffffu;
+            count = walking ? cw >> 16 : 0u;
         }
         test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
         {   // one DDA step, branch-free: mask logic and selects (lanes that are not walking compute along, unused).  The nested
@@ -935,6 +979,7 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
             walking = walking & !stop & inside_grid;
         }
     }
+    if (resume) stamps.mark(8); else stamps.mark(5);
     cellp = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);      // meaningful where `walking` is still set
 }
 
@@ -950,6 +995,19 @@ MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
 
 MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 
+// A material as the shading routines see it: either a pointer to the PreparedMaterial table (LDS in the flat builds,
+// global memory in the strip kernel's grid build) or MatRegs, a copy in registers that arrived with the hit sphere's
+// ShadeRec (pool kernel, grid build).
+MIRT_DEV float4   mat_tex(const PreparedMaterial* m, int k) { return *reinterpret_cast<const float4*>(&m->tex[k][0]); }    // one ds_read_b128
+MIRT_DEV uint32_t mat_flags(const PreparedMaterial* m) { return m->flags; }
+MIRT_DEV float    mat_x(const PreparedMaterial* m) { return m->x; }
+MIRT_DEV float    mat_inv_x(const PreparedMaterial* m) { return m->inv_x; }
+struct MatRegs { uint32_t id; float x, inv_x; uint32_t flags; float4 t0, t1; };
+MIRT_DEV float4   mat_tex(const MatRegs& m, int k) { return make_float4(k ? m.t1.x : m.t0.x, k ? m.t1.y : m.t0.y, k ? m.t1.z : m.t0.z, k ? m.t1.w : m.t0.w); }
+MIRT_DEV uint32_t mat_flags(const MatRegs& m) { return m.flags; }
+MIRT_DEV float    mat_x(const MatRegs& m) { return m.x; }
+MIRT_DEV float    mat_inv_x(const MatRegs& m) { return m.inv_x; }
+
 // Albedo of texture k of a material at a hit with outward normal n: sphereIntersection's (u,v)
 // (wgsl:434-437) fed to textureLookup (wgsl:377-387).
 // 1x1 textures — every colour material in the reference's scenes — take a shortcut that is
@@ -958,10 +1016,11 @@ MIRT_DEV f3 reflect3(f3 v, f3 n) { return fma3(-(2.0f * dot(v, n)), n, v); }
 // n.x < 0 and |n.z| <= ~5e-7 |n.x|; 1-v reaches 1.0 only for acos(-n.y) < 1e-7, i.e. n.y <= -1.
 // The guards below are 20x / 1e-6 wider than that (and false for NaN), and the rare lanes they
 // catch run the full formula.
-MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, TexelTile* T = nullptr)
+template <class M>
+MIRT_DEV f3 albedo_at(const RenderArgs& A, const M& m, int k, f3 n, TexelTile* T = nullptr)
 {
-    const float4 t4 = *reinterpret_cast<const float4*>(&m->tex[k][0]);    // one ds_read_b128 (m lives in LDS)
-    const bool one = (m->flags >> k) & 1u;
+    const float4 t4 = mat_tex(m, k);
+    const bool one = (mat_flags(m) >> k) & 1u;
     // plain mask logic (no short-circuit) so that the shortcut is straight-line code; the full lookup sits
     // behind ONE wave-uniform, rarely taken branch
     const bool fast = one & (n.y > -0.999999f) & ((n.x >= 0.0f) | (abs_(n.z) > 1.0e-5f * abs_(n.x)));
@@ -983,7 +1042,8 @@ MIRT_DEV f3 albedo_at(const RenderArgs& A, const PreparedMaterial* m, int k, f3 
 }
 
 // scatterLambertian (wgsl:204-242): cosine-weighted direction around n through the Pixar ONB
-MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m, int k, f3 n, Rng& rng, f3& dir, f3& atten, TexelTile* T = nullptr)
+template <class M>
+MIRT_DEV void scatter_lambertian(const RenderArgs& A, const M& m, int k, f3 n, Rng& rng, f3& dir, f3& atten, TexelTile* T = nullptr)
 {
     const float phi = rng.next_scaled(kTwoPi * 0x1p-32f);      // 2 pi r1 (r1 is used nowhere else)
     const float r2 = rng.next();
@@ -1018,26 +1078,29 @@ MIRT_DEV void scatter_lambertian(const RenderArgs& A, const PreparedMaterial* m,
 
 // The five scatter routines of scatterRay (wgsl:174-314), one function each so that the pool
 // kernel can run exactly one of them per wave.  rd = incoming direction, hp/hn = hit point/normal.
-MIRT_DEV void shade_lambertian(const RenderArgs& A, const PreparedMaterial* m, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
+template <class M>
+MIRT_DEV void shade_lambertian(const RenderArgs& A, const M& m, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {
     scatter_lambertian(A, m, 0, hn, rng, ndir, att, T);
 }
 
-MIRT_DEV void shade_metal(const RenderArgs& A, const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
+template <class M>
+MIRT_DEV void shade_metal(const RenderArgs& A, const M& m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {   // scatterMetal wgsl:244-248
     const f3 refl = reflect3(rd, hn);
     const f3 rs = rand_in_unit_sphere(rng);
-    ndir = fma3(m->x, rs, refl);
+    ndir = fma3(mat_x(m), rs, refl);
     att = albedo_at(A, m, 0, hn, T);
 }
 
-MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
+template <class M>
+MIRT_DEV void shade_dielectric(const M& m, f3 rd, f3 hn, Rng& rng, f3& ndir, f3& att)
 {   // scatterDielectric wgsl:250-292; the Schlick draw is consumed and the reflection discarded (wgsl:266-273)
     const float dn = dot(rd, hn);
     const f3 uvn = normalize(rd);
     const bool inside = dn > 0.0f;
     const f3 outn = inside ? -hn : hn;
-    const float ratio = inside ? m->x : m->inv_x;
+    const float ratio = inside ? mat_x(m) : mat_inv_x(m);
     const float dt = dot(uvn, outn);
     const float disc = fma_(-(ratio * ratio), fma_(-dt, dt, 1.0f), 1.0f);
     // both outcomes in straight-line code and a select (no divergent if/else): total internal reflection
@@ -1054,7 +1117,8 @@ MIRT_DEV void shade_dielectric(const PreparedMaterial* m, f3 rd, f3 hn, Rng& rng
     att = mk(1, 1, 1);
 }
 
-MIRT_DEV void shade_checkerboard(const RenderArgs& A, const PreparedMaterial* m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
+template <class M>
+MIRT_DEV void shade_checkerboard(const RenderArgs& A, const M& m, f3 hp, f3 hn, Rng& rng, f3& ndir, f3& att, TexelTile* T = nullptr)
 {   // scatterCheckerboard wgsl:300-307: sign of sin(5x)sin(5y)sin(5z) from the signs of the factors
     const bool negative = sin_product_negative(5.0f * hp.x, 5.0f * hp.y, 5.0f * hp.z);
     scatter_lambertian(A, m, negative ? 0 : 1, hn, rng, ndir, att, T);
@@ -1065,6 +1129,23 @@ MIRT_DEV void shade_missing(f3 hn, Rng& rng, f3& ndir, f3& att)
     const f3 rs = rand_in_unit_sphere(rng);
     ndir = hn + rs;
     att = mk(0.9921f, 0.24705f, 0.57254f);
+}
+
+// scatterRay's switch (wgsl:174-202) for kernels that shade per lane (strip kernel; pool kernel, grid build).  `counted` = this lane
+// holds a real path (the pool kernel runs the routines on idle lanes too).
+struct Scattered { f3 dir, att; };
+template <bool COUNT, class M>
+MIRT_DEV Scattered shade_by_id(const RenderArgs& A, const M& m, uint32_t id, bool counted, f3 rd, f3 hp, f3 hn, Rng& rng, Work<COUNT>& work)
+{
+    f3 ndir = rd, att = mk(1, 1, 1);
+    switch (id) {
+    case 0u: if (counted) work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
+    case 1u: if (counted) work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
+    case 2u: if (counted) work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
+    case 3u: if (counted) work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
+    default: if (counted) work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
+    }
+    return Scattered{ ndir, att };
 }
 
 // radiance() wgsl:316-343, one channel of the Hosek-Wilkie state held in LDS
@@ -1165,17 +1246,10 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
                 const f3 hp = fma3(closest, rd, ro);
                 const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
                 const PreparedMaterial* m = &S.pmats[sp.material_idx];
-                f3 ndir, att;
-                switch (m->id) {    // scatterRay wgsl:174-202
-                case 0u: work.add(kCntScatter0); shade_lambertian(A, m, hn, rng, ndir, att); break;
-                case 1u: work.add(kCntScatter1); shade_metal(A, m, rd, hn, rng, ndir, att); break;
-                case 2u: work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
-                case 3u: work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
-                default: work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
-                }
+                const Scattered sc = shade_by_id<COUNT>(A, m, m->id, true, rd, hp, hn, rng, work);
                 ro = hp;
-                rd = ndir;
-                thr = thr * att;
+                rd = sc.dir;
+                thr = thr * sc.att;
             } else {
                 work.add(kCntSky);
                 color = sky_color<HOSEK>(S, rd);
@@ -1312,14 +1386,6 @@ constexpr uint32_t OP_NONE = 7, kMaxQueues = 6;
 #define MIRT_FF_MIN 64
 #endif
 constexpr uint32_t kFastForwardMin = MIRT_FF_MIN;
-// pool kernel, grid builds: cells a path may visit in the step that starts its walk / in an OP_WALK step that resumes it
-#ifndef MIRT_WALK_FRESH
-#define MIRT_WALK_FRESH 3
-#endif
-#ifndef MIRT_WALK_RESUME
-#define MIRT_WALK_RESUME 3
-#endif
-constexpr uint32_t kWalkCellsFresh = MIRT_WALK_FRESH, kWalkCellsResume = MIRT_WALK_RESUME;
 
 // ------------------------------------------------------------------------------------------
 // render_pt_pool — wave-private path pool: every wave-instruction runs ONE shading routine
@@ -1609,10 +1675,14 @@ static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bo
 #ifdef MIRT_FAST_MATH
     if (count) return hipErrorInvalidValue;
 #else
-    if (count) {                                // the counting build exists for the largest geometry only
-        if (slots != kGridPoolSlotChoices[0]) return hipErrorInvalidValue;
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, false, 1, true>, g, b, a, stream);
+    if (count) {                                // counting builds exist for the two largest geometries
+        if (slots == kGridPoolSlotChoices[0])
+            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, true, 1, true>, g, b, a, stream)
+                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, false, 1, true>, g, b, a, stream);
+        if (slots == kGridPoolSlotChoices[1])
+            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, true, 1, true>, g, b, a, stream)
+                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, false, 1, true>, g, b, a, stream);
+        return hipErrorInvalidValue;
     }
 #endif
     if (slots == kGridPoolSlotChoices[0])
@@ -1621,8 +1691,11 @@ static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bo
     if (slots == kGridPoolSlotChoices[1])
         return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, true, 1, true>, g, b, a, stream)
                      : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, false, 1, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, true, 1, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, false, 1, true>, g, b, a, stream);
+    if (slots == kGridPoolSlotChoices[2])
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, false, 1, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], 4, false, true, 1, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], 4, false, false, 1, true>, g, b, a, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
@@ -1672,9 +1745,9 @@ PoolConfig pool_config(uint32_t i, uint32_t nq)
 PoolConfig pool_config_grid(size_t lds_for_pools)
 {
     const uint32_t waves = kGridPoolThreads / 64;
-    const uint32_t bytes[3] = { WavePoolLayout<kGridPoolSlotChoices[0], 1, true>::kBytes * waves, WavePoolLayout<kGridPoolSlotChoices[1], 1, true>::kBytes * waves,
-                                WavePoolLayout<kGridPoolSlotChoices[2], 1, true>::kBytes * waves };
-    for (int i = 0; i < 3; ++i)
+    const uint32_t bytes[4] = { WavePoolLayout<kGridPoolSlotChoices[0], 1, true>::kBytes * waves, WavePoolLayout<kGridPoolSlotChoices[1], 1, true>::kBytes * waves,
+                                WavePoolLayout<kGridPoolSlotChoices[2], 1, true>::kBytes * waves, WavePoolLayout<kGridPoolSlotChoices[3], 1, true>::kBytes * waves };
+    for (int i = 0; i < 4; ++i)
         if (bytes[i] <= lds_for_pools) return PoolConfig{ kGridPoolThreads, kGridPoolSlotChoices[i], bytes[i] };
     return PoolConfig{ kGridPoolThreads, 0, 0 };
 }
