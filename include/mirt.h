@@ -187,7 +187,11 @@ typedef struct MirtParams {
      * stream for `num_samples_per_pixel` = n: frame f = sample / n + 1 seeds the pixel's RNG once (initRng,
      * wgsl:498-502) and its n samples draw from that one stream in turn (samplePixel, wgsl:105-122), exactly as
      * Raytracer::render_frame advances (mod.rs:303-351, 626-670).  Needs spp % n == 0 and sample_begin % n == 0;
-     * runs on the lane-per-pixel schedule (a pixel's samples are then sequentially dependent). */
+     * runs on the lane-per-pixel schedule (a pixel's samples are then sequentially dependent).  Frame numbers count from
+     * sample 0 of the accumulation: the reference's frame_number survives render_progress.reset() (mod.rs:284, 385), so
+     * only its first accumulation after start-up is reproduced number for number (a caller that wants the later ones
+     * passes sample_begin = n * frames rendered before, to mirt_ctx_render*; mirt_ctx_accum_add always continues at
+     * the samples it holds). */
     uint32_t frame_spp;
     uint32_t _reserved;    /* 0 */
 } MirtParams;
@@ -233,7 +237,18 @@ typedef enum MirtStatus {
     MIRT_ERR_TEXEL_RANGE          = -15, /* a descriptor reaches past n_texels */
     MIRT_ERR_OUT_BUFFER           = -16, /* out_len too small */
     MIRT_ERR_NO_SCENE             = -17,
-    MIRT_ERR_SCENE_TOO_LARGE      = -18, /* spheres+materials do not fit the LDS budget */
+    /* The kernels keep the scene in LDS (160 KB per CU, 120 KB = 122 880 B of it for the scene): a scene is accepted if one
+     * of two layouts fits, else mirt_ctx_set_scene fails with this code.  (The reference's own buffers are bounded by wgpu's
+     * 512 MiB storage-buffer limit, main.rs:421-481; BASELINE's largest scene has 484 spheres.)
+     *   flat layout (every mode and flag): 96 + 32 * n_spheres + 48 * n_materials + 144 <= 122 880 bytes
+     *       -- e.g. 3 831 spheres with one material;
+     *   grid layout (MIRT_MODE_PT only, scenes of >= 32 spheres of which at most 64 exceed 4 median radii): n_spheres <= 4 095
+     *       (12-bit sphere ids in a path's state word), <= 8 192 cells (the host coarsens the cells to stay below), <= 65 535
+     *       cell entries, and 240 + blob <= 122 880 bytes with blob ~ 17 * n_spheres + 4 * cells + 2 * entries.  Grids with a
+     *       dimension above 1 024 cells (10-bit cell coordinates) run the strip kernel instead of the pooled one.
+     * A scene that fits ONLY the grid layout renders in path-traced mode with default flags; a render call in parity mode, or
+     * with MIRT_FLAG_COUNT_WORK without MIRT_FLAG_COUNT_GRID, or with MIRT_FLAG_NO_GRID, returns this code. */
+    MIRT_ERR_SCENE_TOO_LARGE      = -18,
     MIRT_ERR_FRAME_SPP            = -19, /* frame_spp does not divide spp / sample_begin */
     MIRT_ERR_NO_DEVICE            = -20,
     MIRT_ERR_HIP                  = -21,

@@ -105,6 +105,29 @@ pub const MIRT_FLAG_COUNT_GRID: u32 = 1 << 7;
 pub const MIRT_FLAG_FAST_MATH: u32 = 1 << 8;
 pub const MIRT_FLAG_TEXEL_TILES: u32 = 1 << 9;
 
+// MirtStatus (include/mirt.h): 0 = ok, negative = error; mirt_status_string() names them, mirt_last_error() explains the last one
+pub const MIRT_OK: c_int = 0;
+pub const MIRT_ERR_MAX_SAMPLES_MULTIPLE: c_int = -1;
+pub const MIRT_ERR_VIEWPORT_SIZE: c_int = -2;
+pub const MIRT_ERR_VFOV_RANGE: c_int = -3;
+pub const MIRT_ERR_APERTURE_RANGE: c_int = -4;
+pub const MIRT_ERR_FOCUS_DISTANCE: c_int = -5;
+pub const MIRT_ERR_SKY: c_int = -6;
+pub const MIRT_ERR_NULL_POINTER: c_int = -10;
+pub const MIRT_ERR_SPP_ZERO: c_int = -11;
+pub const MIRT_ERR_BAD_MODE: c_int = -12;
+pub const MIRT_ERR_BAD_ROWS: c_int = -13;
+pub const MIRT_ERR_MATERIAL_INDEX: c_int = -14;
+pub const MIRT_ERR_TEXEL_RANGE: c_int = -15;
+pub const MIRT_ERR_OUT_BUFFER: c_int = -16;
+pub const MIRT_ERR_NO_SCENE: c_int = -17;
+pub const MIRT_ERR_SCENE_TOO_LARGE: c_int = -18;
+pub const MIRT_ERR_FRAME_SPP: c_int = -19;
+pub const MIRT_ERR_NO_DEVICE: c_int = -20;
+pub const MIRT_ERR_HIP: c_int = -21;
+pub const MIRT_ERR_ALLOC: c_int = -22;
+pub const MIRT_ERR_IMAGE_DECODE: c_int = -23;
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct MirtParams {

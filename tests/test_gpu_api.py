@@ -322,3 +322,45 @@ def test_set_scene_is_failure_atomic(gpu_ctx):
     many = [m.Sphere.new((0, 0, -5), 0.1, 0).to_c()] * 5000
     assert _abi.STATUS[_status(lambda: gpu_ctx.set_scene(m.SceneData(cam, many, mats, tex)))] == "MIRT_ERR_SCENE_TOO_LARGE"
     assert_images_equal(gpu_ctx.render(p), want, "old scene intact after a rejected set_scene")
+
+
+def _soup(n_small, n_large, spread):
+    """n_small spheres of radius 0.01 on a jittered lattice + n_large of radius 1 (> 4 median radii: 'big' for the grid builder)."""
+    rng = np.random.default_rng(5)
+    side = int(np.ceil(np.sqrt(max(1, n_small))))
+    sph = []
+    for i in range(n_small):
+        sph.append(m.Sphere.new((spread * (i % side) / side - spread / 2 + 0.001 * rng.random(), 0.0, spread * (i // side) / side - spread / 2), 0.01, 0).to_c())
+    for i in range(n_large):
+        sph.append(m.Sphere.new((float(i) * 3.0, 5.0, -20.0), 1.0, 0).to_c())
+    return sph
+
+
+def test_scene_limits_at_the_boundary(gpu_ctx):
+    """include/mirt.h, MIRT_ERR_SCENE_TOO_LARGE: the flat layout holds 96 + 32 n + 48 m + 144 <= 122 880 bytes -- 3 831 spheres
+    with one material --, the grid layout at most 4 095 spheres; a scene that fits only the grid layout renders in path-traced
+    mode and refuses the launches that need the flat scan."""
+    mats, tex = m.flatten_materials([m.Material.Lambertian(albedo=m.Texture.new_from_color((0.5, 0.5, 0.5)))])
+    cam = simple_camera(32, 16)
+    # 100 large spheres make the grid builder give up (more than 64 'big' ones): only the flat layout is left
+    ok = m.SceneData(cam, _soup(3731, 100, 4.0), mats, tex)
+    gpu_ctx.set_scene(ok)                                           # 3 831 spheres: fits exactly
+    assert gpu_ctx.render(m.make_params(32, 16, 1, mode=m.MIRT_MODE_PT, num_bounces=2)).shape == (16, 32, 4)
+    with pytest.raises(m.MirtError) as e:
+        gpu_ctx.set_scene(m.SceneData(cam, _soup(3732, 100, 4.0), mats, tex))       # one more: 32 bytes over
+    assert e.value.status == _abi.MIRT_ERR_SCENE_TOO_LARGE
+    # a failed set_scene leaves the previous scene in place (failure-atomic)
+    assert gpu_ctx.render(m.make_params(32, 16, 1, mode=m.MIRT_MODE_PT, num_bounces=2)).shape == (16, 32, 4)
+    # 4 000 small spheres: too many for the flat layout, fine for the grid layout
+    grid_only = m.SceneData(cam, _soup(4000, 0, 8.0), mats, tex)
+    gpu_ctx.set_scene(grid_only)
+    assert gpu_ctx.render(m.make_params(32, 16, 2, mode=m.MIRT_MODE_PT, num_bounces=2)).shape == (16, 32, 4)
+    assert "true>" in gpu_ctx.last_kernel() or ",true," in gpu_ctx.last_kernel()          # a grid build ran
+    for p in (m.make_params(32, 16, 2, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_NO_GRID), m.make_params(32, 16, 2, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_COUNT_WORK)):
+        with pytest.raises(m.MirtError) as e:
+            gpu_ctx.render(p)
+        assert e.value.status == _abi.MIRT_ERR_SCENE_TOO_LARGE
+    # 4 096 spheres: past the 12-bit sphere ids of the grid layout as well
+    with pytest.raises(m.MirtError) as e:
+        gpu_ctx.set_scene(m.SceneData(cam, _soup(4096, 0, 8.0), mats, tex))
+    assert e.value.status == _abi.MIRT_ERR_SCENE_TOO_LARGE

@@ -474,6 +474,26 @@ def test_frame_stream_param_errors(gpu_ctx, oracle):
         assert oracle.render_status(sd.as_c(), p) == m._abi.MIRT_ERR_FRAME_SPP
 
 
+def test_accumulation_refuses_a_frame_stream_that_would_start_mid_frame(gpu_ctx):
+    """mirt_ctx_accum_add continues at the samples accumulated so far, whatever sample_begin the caller passes: that count must be
+    a multiple of frame_spp, or the lane-per-pixel kernel would draw from an unseeded stream until the next frame boundary."""
+    sd = scene_data("three_spheres", 24, 16)
+    gpu_ctx.set_scene(sd)
+    p4 = m.make_params(24, 16, 4, mode=m.MIRT_MODE_PT, frame_spp=2)
+    gpu_ctx.accum_reset(p4)
+    gpu_ctx.accum_add(p4)
+    assert gpu_ctx.accum_samples() == 4
+    p3 = m.make_params(24, 16, 3, mode=m.MIRT_MODE_PT, frame_spp=3)          # valid on its own (3 | 3, 3 | 0) ...
+    with pytest.raises(m.MirtError) as e:
+        gpu_ctx.accum_add(p3)                                               # ... but 4 samples are in the buffer
+    assert e.value.status_name == "MIRT_ERR_FRAME_SPP" and gpu_ctx.accum_samples() == 4
+    gpu_ctx.accum_add(p4)                                                   # the buffer is still usable
+    assert gpu_ctx.accum_samples() == 8
+    gpu_ctx.accum_reset(p3)
+    gpu_ctx.accum_add(p3)
+    assert gpu_ctx.accum_samples() == 3
+
+
 def test_raytracer_render_frame_with_the_reference_stream(oracle):
     scene, cam = m.scenes.three_spheres()
     rp = m.RenderParams(camera=cam, viewport_size=(64, 40), sampling=m.SamplingParams(8, 2, 8))

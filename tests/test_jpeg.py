@@ -104,3 +104,20 @@ def test_reference_assets_decode_to_the_committed_texel_fixtures(name, fixture):
     t = m.Texture.new_from_image(str(REF_ASSETS / name))
     assert t.dimensions() == (1024, 512)
     assert np.array_equal(t.as_slice(), m.Texture.new_from_rgb8(want).as_slice())
+
+
+def test_a_header_that_claims_more_pixels_than_the_file_can_code_is_refused():
+    """Untrusted input: the decoder allocates its coefficient planes from the SOF header, so a short file must not be able to
+    claim a huge frame (16384 x 16384 from a few hundred bytes would be 1.5 GB).  The bound is 4096 pixels per byte of file;
+    the header-only query still answers."""
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, format="JPEG", quality=50)
+    data = bytearray(buf.getvalue())
+    i = data.index(b"\xff\xc0")                      # SOF0: length(2) precision(1) height(2) width(2)
+    data[i + 5:i + 9] = bytes([0x40, 0x00, 0x40, 0x00])     # 16384 x 16384
+    assert m.jpeg_info(bytes(data)) == (16384, 16384)
+    with pytest.raises(m.MirtError) as e:
+        m.decode_jpeg(bytes(data))
+    assert e.value.status_name == "MIRT_ERR_IMAGE_DECODE" and "too large" in str(e.value)

@@ -1005,6 +1005,10 @@ int mirt_ctx_accum_add(MirtContext* c, const MirtParams* p, void* hip_stream)
     HIP_TRY(hipSetDevice(c->device));
     MirtParams q = *p;
     q.sample_begin = c->accum_samples;                  // continue the RNG stream where the last frame stopped
+    // check_params saw the CALLER's sample_begin; the one that counts is this one.  A caller that changes frame_spp between adds
+    // without a reset would start mid-frame: the lane-per-pixel kernel seeds only at frame boundaries, so the sums would be wrong silently.
+    if (q.frame_spp != 0 && q.sample_begin % q.frame_spp != 0)
+        return fail(MIRT_ERR_FRAME_SPP, "frame_spp %u does not divide the %u samples accumulated so far: reset first", q.frame_spp, q.sample_begin);
     rc = launch_render(c, &q, nullptr, hip_stream ? (hipStream_t)hip_stream : c->stream, c->d_accum);
     if (rc == MIRT_OK) c->accum_samples += p->spp;
     return rc;

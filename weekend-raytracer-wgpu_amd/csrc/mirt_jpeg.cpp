@@ -174,7 +174,11 @@ struct Decoder {
                 progressive = mk == 0xc2;
                 have_frame = true;
                 if (header_only) return kOk;
-                if ((uint64_t)width * height > (1ull << 28)) return fail("image too large");
+                // untrusted input: the coefficient and pixel planes are allocated from the header alone, before any entropy data is
+                // read.  Bound the frame by 2^28 pixels AND by the file: the densest legal coding (two 1-bit codes per block, 32x32-pixel
+                // MCUs of 18 blocks) is about 230 pixels per byte, so 4096 pixels per byte of file refuses only headers that lie
+                // (a 200-byte file claiming 16384 x 16384 would otherwise allocate 1.5 GB).
+                if ((uint64_t)width * height > (1ull << 28) || (uint64_t)width * height > 4096ull * (uint64_t)len + 65536ull) return fail("image too large");
                 const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
                 for (int i = 0; i < ncomp; ++i) {
                     Component& c = comp[i];
@@ -322,7 +326,7 @@ struct Decoder {
         if (!progressive) {
             const int t = decode_symbol(b, dc[c.td]);
             const int diff = t ? extend(b.get(t), t) : 0;
-            c.pred += diff;
+            c.pred = (int)((unsigned)c.pred + (unsigned)diff);       // wraps instead of overflowing on a crafted stream (valid files: |DC| <= 2^15)
             blk[0] = (int16_t)c.pred;
             for (int k = 1; k < 64;) {
                 const int rs = decode_symbol(b, ac[c.ta]);
@@ -339,8 +343,8 @@ struct Decoder {
             if (ah == 0) {                                     // DC, first pass
                 const int t = decode_symbol(b, dc[c.td]);
                 const int diff = t ? extend(b.get(t), t) : 0;
-                c.pred += diff;
-                blk[0] = (int16_t)(c.pred * (1 << al));
+                c.pred = (int)((unsigned)c.pred + (unsigned)diff);
+                blk[0] = (int16_t)((unsigned)c.pred << al);
             } else if (b.get(1)) {                             // DC, refinement
                 blk[0] = (int16_t)(blk[0] | (1 << al));
             }

@@ -486,7 +486,13 @@ class Raytracer:
         """`reference_stream=True` makes `render_frame` (and `render`) draw the samples of one frame from ONE RNG
         stream per pixel, seeded with the frame number -- the reference's initRng / samplePixel (wgsl:498-502,
         105-122) for `num_samples_per_pixel` samples per frame (MirtParams.frame_spp).  The default keeps one stream
-        per sample (frame_number = sample + 1), which does not depend on how samples are grouped into frames."""
+        per sample (frame_number = sample + 1), which does not depend on how samples are grouped into frames.
+
+        Scope of the match: frame f of an accumulation seeds with f = accumulated_samples / n + 1, i.e. every accumulation
+        starts at frame 1.  The reference's `frame_number` (mod.rs:284, 350) is NOT reset by `render_progress.reset()`
+        (mod.rs:385) and keeps counting on completed frames, so only the FIRST accumulation after construction draws the
+        reference's numbers; after `set_render_params` (a camera move) the streams differ by a frame offset -- equally
+        valid samples, but not the reference's: that case is parity-unpinned (nothing in the reference pins it either)."""
         render_params.validate()                                   # mod.rs:44-47
         self.reference_stream = reference_stream
         self.render_params = render_params
