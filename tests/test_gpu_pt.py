@@ -395,6 +395,47 @@ def test_grid_nearest_hit_equals_flat_scan(gpu_ctx, oracle, seed, n, spread):
     print(f"grid {t_grid:.2f} ms, flat {t_flat:.2f} ms")
 
 
+@pytest.mark.parametrize("case", ["rtiow", "row_of_spheres_along_the_view", "wide_lens", "narrow_frame", "inside_a_sphere", "behind_and_beside"])
+def test_camera_ray_candidate_lists(gpu_ctx, oracle, case):
+    """Pooled kernel, grid build: the camera rays of a strip scan a per-strip list of the spheres their bundle can touch instead of
+    walking the grid (csrc strip_candidates).  The list must be a superset of what any of those rays hits -- images and every work
+    counter equal to the oracle's flat scan -- including the fall-backs: more than 16 candidates (spheres lined up along the view),
+    a lens too wide for a thin bundle, strips that wrap into the next image row, a camera inside a sphere, spheres behind the eye
+    and just beside the bundle."""
+    rng = np.random.default_rng(77)
+    spheres, gm, tex = _sphere_soup(rng, 120, 4.0, 0.08, 0.3)
+    w, h, spp, aperture, eye, yaw, pitch = 160, 48, 24, 0.05, (9.0, 1.2, 7.0), 218.0, -7.0
+    if case == "rtiow":
+        sd = scene_data("rtiow_final", 192, 64)
+        w, h = 192, 64
+    else:
+        if case == "row_of_spheres_along_the_view":
+            direction = np.float32([np.cos(np.radians(pitch)) * np.sin(np.radians(yaw)), np.sin(np.radians(pitch)), np.cos(np.radians(pitch)) * np.cos(np.radians(yaw))])
+            spheres += [m.Sphere.new(np.float32(eye) + direction * (2.0 + 0.5 * i) + rng.normal(size=3) * 0.02, 0.05, int(i % 3)).to_c() for i in range(40)]
+        if case == "wide_lens":
+            aperture = 1.0
+        if case == "narrow_frame":
+            w, h = 24, 90                              # 24 pixels per row: every other 16-pixel strip wraps into the next row
+        if case == "inside_a_sphere":
+            spheres.append(m.Sphere.new(eye, 0.8, 2).to_c())           # the eye sits at the centre of a glass sphere
+        if case == "behind_and_beside":
+            spheres += [m.Sphere.new((eye[0] + 0.3 * i, eye[1] + 0.2, eye[2] + 0.4 * i), 0.25, 1).to_c() for i in range(1, 8)]
+        fc = m.FlyCameraController(np.float32(eye), m.Angle.degrees(yaw), m.Angle.degrees(pitch), 35.0, aperture, 9.0)
+        sd = m.SceneData(m.GpuCamera.new(fc.renderer_camera(), (w, h)).c, spheres, gm, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=m.MIRT_FLAG_KERNEL_POOL)
+    want = oracle.render(sd, m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=m.MIRT_FLAG_COUNT_WORK))
+    want_counts = oracle.stats()
+    got = gpu_ctx.render(p)
+    assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and gpu_ctx.last_kernel().endswith(",true>")
+    assert_images_equal(got, want, case)
+    pc = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=m.MIRT_FLAG_KERNEL_POOL | m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)
+    assert_images_equal(gpu_ctx.render(pc), want, case + " (counting build)")
+    st = gpu_ctx.stats()
+    for k in ("rays", "hits", "sky_misses", "scatter"):                   # the paths are the flat scan's, ray by ray
+        assert st[k] == want_counts[k], (k, st[k], want_counts[k])
+
+
 def test_grid_with_rays_parallel_to_axes(gpu_ctx, oracle):
     """Axis-aligned rays (zero direction components) through the grid: the DDA's 1/0 handling."""
     rng = np.random.default_rng(77)

@@ -26,6 +26,7 @@ ap.add_argument("--lib", default=str(ROOT / "tools/_scratch/libs/libmirt_diag.so
 ap.add_argument("--scene", default="rtiow_final")
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--flags", type=lambda v: int(v, 0), default=0, help="extra MIRT_FLAG_* bits (e.g. 0x20 = force the pooled kernel)")
 ap.add_argument("--plain", action="store_true", help="a plain launch (no counting build): for the -DMIRT_DIAG_STAMPS build, which prints MIRT_STAMPS")
 a = ap.parse_args()
 w, h = map(int, a.size.split("x"))
@@ -36,7 +37,7 @@ assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
 sd = scene_data(a.scene, w, h)
 sc = sd.as_c()
 assert lib.mirt_ctx_set_scene(ctx, C.byref(sc)) == 0, lib.mirt_last_error()
-p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=0 if a.plain else (m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID))
+p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=a.flags | (0 if a.plain else (m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)))
 out = np.empty((h, w, 4), np.uint8)
 assert lib.mirt_ctx_render(ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), out.nbytes) == 0, lib.mirt_last_error()
 st = _abi.MirtStats()

@@ -205,6 +205,7 @@ struct Tuning {
     double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
     double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
     int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
+    int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
 };
 
 Tuning read_tuning()
@@ -219,6 +220,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
     if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
     if (const char* e = std::getenv("MIRT_PINHOLE")) t.pinhole = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
 }
@@ -800,6 +802,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
     a.shade = (use_grid && c->have_shade) ? c->d_shade : nullptr;
     a.grid_pool_slots = pool_grid ? pcg.slots : 0u;
+    a.strip_cand = (pool_grid && tune.strip_cand != 0) ? 1u : 0u;
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "

@@ -1376,6 +1376,70 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
     }
 }
 
+// Grid builds: the camera rays of one strip -- up to 16 pixels x spp samples, 39 % of all rays of the RTIOW scene -- leave a lens of a
+// few centimetres through a footprint of a few pixels on the focal plane: one thin bundle.  The wave therefore selects, ONCE per strip, the
+// spheres that bundle can touch (strip_candidates below: a conservative bound, a superset is all that is needed), and the primary rays of
+// the strip scan that short list -- typically the ground and two or three spheres -- instead of paying the always-tested big spheres, the
+// clip, the grid entry and a walk of 4-5 cells each (camera rays graze the slab of small spheres: they are the longest walkers).  The
+// nearest hit over a superset of the spheres a ray can hit is the nearest hit over all spheres, test by test the same arithmetic
+// (test_sphere) and tie-break: identical images.  More than kMaxCand candidates, a strip that wraps into the next row or a bundle that is
+// not thin: the strip's camera rays take the grid like every other ray.
+constexpr uint32_t kMaxCand = 16, kNoCand = 0xffffffffu;
+constexpr uint32_t kCandBytes = 48;       // u16 ids [kMaxCand] | u32 count (kNoCand: use the grid) | pad
+
+// The candidate list of a strip's camera rays (see above).  Pixels [x0, x0 + n) of image row y; all lanes take part.
+// A camera ray (wgsl:456-478) starts at O = eye + e, |e| <= R (the lens), and aims at a point F of the strip's footprint on the
+// focal plane, |F - Fc| <= delta (Fc its centre): P(t) = O + t (F - O) = eye + t (Fc - eye) + w with |w| <= t (delta + R) + R.
+// With a = Fc - eye, D = |a|, and for a sphere (c, r): s = (c - eye) . a / D, d = distance of c from the axis.  A hit needs
+// |c - P(t)| <= r for some t >= 0, hence |s - t D| <= r + R + t g and d <= r + R + t g with g = delta + R; the first gives
+// t <= tmax = (s + r + R) / (D - g) (and s + r + R >= 0), the second then d <= r + R + tmax g.  Everything is evaluated with slack
+// (2 % on g, 5 % + 0.01 + 0.001 |c - eye| on the bound) that dwarfs the rounding of these few float operations, and every
+// comparison is written so that a NaN keeps the sphere: the list is a superset by construction.
+MIRT_DEV uint32_t strip_candidates(const RenderArgs& AP, const SceneLds& S, uint32_t x0, uint32_t n, uint32_t y, unsigned short* ids, uint32_t lane)
+{
+    const f3 eye = mk(S.cam[0], S.cam[1], S.cam[2]), hor = mk(S.cam[4], S.cam[5], S.cam[6]), ver = mk(S.cam[8], S.cam[9], S.cam[10]);
+    const f3 cam_u = mk(S.cam[12], S.cam[13], S.cam[14]), cam_v = mk(S.cam[16], S.cam[17], S.cam[18]), llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    const float lens_radius = S.cam[19];
+    const float inv_w = 1.0f / (float)AP.width, inv_h = 1.0f / (float)AP.height;
+    const float u0 = (float)x0 * inv_w, u1 = (float)(x0 + n) * inv_w;
+    const float v1 = 1.0f - (float)y * inv_h, v0 = 1.0f - (float)(y + 1u) * inv_h;
+    const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1), du = 0.5f * (u1 - u0), dv = 0.5f * (v1 - v0);
+    const f3 axis = fma3(vc, ver, fma3(uc, hor, llc)) - eye;
+    const float D = __builtin_sqrtf(dot(axis, axis));
+    const float delta = abs_(du) * __builtin_sqrtf(dot(hor, hor)) + abs_(dv) * __builtin_sqrtf(dot(ver, ver));     // triangle inequality over the corners
+    const float R = 1.5f * abs_(lens_radius) * max_(__builtin_sqrtf(dot(cam_u, cam_u)), __builtin_sqrtf(dot(cam_v, cam_v)));
+    const float g = 1.02f * (delta + R) + 1.0e-6f * D;
+    if (!(D > 0.0f && D < 1.0e30f && g < 0.25f * D)) return kNoCand;          // not a thin bundle (or NaN): no list
+    const float inv_D = 1.0f / D;
+    const f3 ah = inv_D * axis;
+    const float inv_den = 1.0f / (D - g);
+    uint32_t count = 0;
+    for (uint32_t base = 0; base < AP.n_spheres; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool valid = i < AP.n_spheres;
+        const PreparedSphere sp = AP.spheres[valid ? i : 0u];
+        const f3 q = mk(sp.cx, sp.cy, sp.cz) - eye;
+        const float r = abs_(sp.radius);
+        const float s = dot(q, ah), qq = dot(q, q);
+        const float d2 = qq - s * s;
+        const float dperp = __builtin_sqrtf(d2 > 0.0f ? d2 : 0.0f);
+        const float len_q = __builtin_sqrtf(qq);
+        const float margin = 0.01f + 1.0e-3f * len_q;
+        const float reach = s + r + R;
+        const float tmax = (reach > 0.0f ? reach : 0.0f) * inv_den;
+        const float bound = 1.05f * (r + R + tmax * g) + margin;
+        const bool out = (reach < -margin) | (dperp > bound);                    // false for NaN: the sphere stays
+        const bool cand = valid & !out;
+        const unsigned long long mask = ballot_(cand);
+        const uint32_t more = (uint32_t)__popcll(mask);
+        if (count + more > kMaxCand) return kNoCand;                             // wave-uniform
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (cand) ids[count + rank] = (unsigned short)i;
+        count += more;
+    }
+    return count;
+}
+
 // Shading routines a path can wait for: the five scatter routines of scatterRay (wgsl:174-314), identified by
 // min(GpuMaterial.id, 4), and OP_GEN = finish the path (add throughput x sky) + start the next work item.
 // A scene's routines are numbered densely on the host (queue q runs routine RenderArgs.queue_routine[q],
@@ -1416,7 +1480,8 @@ struct WavePoolLayout {
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
     static constexpr uint32_t kOffCell  = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32: grid cell of a path whose walk is cut (GRID)
     static constexpr uint32_t kOffRing  = kOffCell + (GRID ? SLOTS * 4 : 0);  // [kQueues][kRing] u8
-    static constexpr uint32_t kOffTile  = ((kOffRing + kQueues * kRing + 15) / 16) * 16;     // TexelTile: header + 3 colour planes (TILE)
+    static constexpr uint32_t kOffCand  = ((kOffRing + kQueues * kRing + 15) / 16) * 16;     // camera-ray candidates of the strip (GRID): ids + count
+    static constexpr uint32_t kOffTile  = kOffCand + (GRID ? kCandBytes : 0);                // TexelTile: header + 3 colour planes (TILE)
     static constexpr uint32_t kBytes    = kOffTile + (TILE ? ((kTileBytes + 15) / 16) * 16 : 0);
 };
 
