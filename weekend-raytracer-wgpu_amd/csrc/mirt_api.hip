@@ -797,13 +797,17 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     }
     // many-sphere scenes: nearest hit through the uniform grid (strip kernel, non-counting build only:
     // the counting build keeps the reference's flat scan so that its work counters stay comparable)
-    const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes <= (size_t)c->lds_per_block);
+    const bool use_grid = pool_grid || (grid_ok && !pool && scene_lds_g + c->grid_bytes + 4u * 48u <= (size_t)c->lds_per_block);
     a.grid = use_grid ? c->d_grid : nullptr;
     a.grid_bytes = use_grid ? c->grid_bytes : 0u;
     a.shade = (use_grid && c->have_shade) ? c->d_shade : nullptr;
     a.grid_pool_slots = pool_grid ? pcg.slots : 0u;
-    a.strip_cand = (pool_grid && tune.strip_cand != 0) ? 1u : 0u;
-    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 0)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
+    // camera-ray candidate lists (mirt_kernels.hip: strip_candidates): always in the pooled kernel (a list serves 16 pixels x spp rays);
+    // in the strip kernel's lane-per-pixel units (64 pixels x spp) from 4 samples per pixel on -- measured on RTIOW 1080p: 2 spp +2 %
+    // (selecting among 484 spheres costs more than 128 camera rays save), 8 spp -6 %
+    a.strip_cand = (use_grid && tune.strip_cand != 0 && (pool_grid || p->spp >= 4u)) ? 1u : 0u;
+    // (the strip kernel's grid build keeps a camera-ray candidate list per wave behind the blob: 4 waves x 48 bytes)
+    a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 4u * 48u)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)
         return fail(MIRT_ERR_SCENE_TOO_LARGE, "this scene only fits LDS in the grid build of the path-traced mode "
                     "(no parity mode, no MIRT_FLAG_COUNT_WORK / MIRT_FLAG_NO_GRID / MIRT_FLAG_KERNEL_POOL)");
@@ -965,8 +969,8 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
         c->stats.texel_tile_hits[0] = h[mirt::kCntTileHitsPrimary];
         c->stats.texel_tile_hits[1] = h[mirt::kCntTileHitsLater];
 #ifdef MIRT_DIAG_STEPS
-        fprintf(stderr, "MIRT_DIAG steps scatter/gen/walk %llu %llu %llu paths %llu %llu %llu ff_steps %llu traces cut/hit/miss %llu %llu %llu\n",
-                h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27]);
+        fprintf(stderr, "MIRT_DIAG steps scatter/gen/walk %llu %llu %llu paths %llu %llu %llu ff_steps %llu traces cut/hit/miss %llu %llu %llu strips %llu with_list %llu candidates %llu\n",
+                h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
 #endif
 #ifdef MIRT_PROBE_TEXELS
         c->stats.grid_cells = h[12]; c->stats.grid_wave_cells = h[13]; c->stats.lane_iterations = h[14]; c->stats.wave_iterations = h[15];

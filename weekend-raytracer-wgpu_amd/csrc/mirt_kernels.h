@@ -81,7 +81,7 @@ constexpr uint32_t kStripLevels   = 5;    // strip widths 16, 8, 4, 2, 1
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
 constexpr uint32_t kBlockThreads  = 256;  // strip kernels: 4 waves
 #if defined(MIRT_DIAG_STEPS) || defined(MIRT_DIAG_STAMPS)   // diagnosis builds (tools/step_stats.py): ten more counters, printed by mirt_ctx_get_stats
-constexpr uint32_t kNumCounters   = 28;
+constexpr uint32_t kNumCounters   = 31;
 #else
 constexpr uint32_t kNumCounters   = 18;   // u64 work counters (MirtStats order)
 #endif

@@ -1217,6 +1217,70 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
     return (uint32_t)fma_(m, 255.0f, 0.5f);
 }
 
+// Grid builds: the camera rays of one strip -- up to 16 pixels x spp samples, 39 % of all rays of the RTIOW scene -- leave a lens of a
+// few centimetres through a footprint of a few pixels on the focal plane: one thin bundle.  The wave therefore selects, ONCE per strip, the
+// spheres that bundle can touch (strip_candidates below: a conservative bound, a superset is all that is needed), and the primary rays of
+// the strip scan that short list -- typically the ground and two or three spheres -- instead of paying the always-tested big spheres, the
+// clip, the grid entry and a walk of 4-5 cells each (camera rays graze the slab of small spheres: they are the longest walkers).  The
+// nearest hit over a superset of the spheres a ray can hit is the nearest hit over all spheres, test by test the same arithmetic
+// (test_sphere) and tie-break: identical images.  More than kMaxCand candidates, a strip that wraps into the next row or a bundle that is
+// not thin: the strip's camera rays take the grid like every other ray.
+constexpr uint32_t kMaxCand = 16, kNoCand = 0xffffffffu;
+constexpr uint32_t kCandBytes = 48;       // u16 ids [kMaxCand] | u32 count (kNoCand: use the grid) | pad
+
+// The candidate list of a strip's camera rays (see above).  Pixels [x0, x0 + n) of image row y; all lanes take part.
+// A camera ray (wgsl:456-478) starts at O = eye + e, |e| <= R (the lens), and aims at a point F of the strip's footprint on the
+// focal plane, |F - Fc| <= delta (Fc its centre): P(t) = O + t (F - O) = eye + t (Fc - eye) + w with |w| <= t (delta + R) + R.
+// With a = Fc - eye, D = |a|, and for a sphere (c, r): s = (c - eye) . a / D, d = distance of c from the axis.  A hit needs
+// |c - P(t)| <= r for some t >= 0, hence |s - t D| <= r + R + t g and d <= r + R + t g with g = delta + R; the first gives
+// t <= tmax = (s + r + R) / (D - g) (and s + r + R >= 0), the second then d <= r + R + tmax g.  Everything is evaluated with slack
+// (2 % on g, 5 % + 0.01 + 0.001 |c - eye| on the bound) that dwarfs the rounding of these few float operations, and every
+// comparison is written so that a NaN keeps the sphere: the list is a superset by construction.
+MIRT_DEV uint32_t strip_candidates(const RenderArgs& AP, const SceneLds& S, uint32_t x0, uint32_t n, uint32_t y, unsigned short* ids, uint32_t lane)
+{
+    const f3 eye = mk(S.cam[0], S.cam[1], S.cam[2]), hor = mk(S.cam[4], S.cam[5], S.cam[6]), ver = mk(S.cam[8], S.cam[9], S.cam[10]);
+    const f3 cam_u = mk(S.cam[12], S.cam[13], S.cam[14]), cam_v = mk(S.cam[16], S.cam[17], S.cam[18]), llc = mk(S.cam[20], S.cam[21], S.cam[22]);
+    const float lens_radius = S.cam[19];
+    const float inv_w = 1.0f / (float)AP.width, inv_h = 1.0f / (float)AP.height;
+    const float u0 = (float)x0 * inv_w, u1 = (float)(x0 + n) * inv_w;
+    const float v1 = 1.0f - (float)y * inv_h, v0 = 1.0f - (float)(y + 1u) * inv_h;
+    const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1), du = 0.5f * (u1 - u0), dv = 0.5f * (v1 - v0);
+    const f3 axis = fma3(vc, ver, fma3(uc, hor, llc)) - eye;
+    const float D = __builtin_sqrtf(dot(axis, axis));
+    const float delta = abs_(du) * __builtin_sqrtf(dot(hor, hor)) + abs_(dv) * __builtin_sqrtf(dot(ver, ver));     // triangle inequality over the corners
+    const float R = 1.5f * abs_(lens_radius) * max_(__builtin_sqrtf(dot(cam_u, cam_u)), __builtin_sqrtf(dot(cam_v, cam_v)));
+    const float g = 1.02f * (delta + R) + 1.0e-6f * D;
+    if (!(D > 0.0f && D < 1.0e30f && g < 0.25f * D)) return kNoCand;          // not a thin bundle (or NaN): no list
+    const float inv_D = 1.0f / D;
+    const f3 ah = inv_D * axis;
+    const float inv_den = 1.0f / (D - g);
+    uint32_t count = 0;
+    for (uint32_t base = 0; base < AP.n_spheres; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool valid = i < AP.n_spheres;
+        const PreparedSphere sp = AP.spheres[valid ? i : 0u];
+        const f3 q = mk(sp.cx, sp.cy, sp.cz) - eye;
+        const float r = abs_(sp.radius);
+        const float s = dot(q, ah), qq = dot(q, q);
+        const float d2 = qq - s * s;
+        const float dperp = __builtin_sqrtf(d2 > 0.0f ? d2 : 0.0f);
+        const float len_q = __builtin_sqrtf(qq);
+        const float margin = 0.01f + 1.0e-3f * len_q;
+        const float reach = s + r + R;
+        const float tmax = (reach > 0.0f ? reach : 0.0f) * inv_den;
+        const float bound = 1.05f * (r + R + tmax * g) + margin;
+        const bool out = (reach < -margin) | (dperp > bound);                    // false for NaN: the sphere stays
+        const bool cand = valid & !out;
+        const unsigned long long mask = ballot_(cand);
+        const uint32_t more = (uint32_t)__popcll(mask);
+        if (count + more > kMaxCand) return kNoCand;                             // wave-uniform
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (cand) ids[count + rank] = (unsigned short)i;
+        count += more;
+    }
+    return count;
+}
+
 // ------------------------------------------------------------------------------------------
 // render_pt_strip — one path per lane, per-lane material switch
 // ------------------------------------------------------------------------------------------
@@ -1224,8 +1288,10 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
 // rayColor wgsl:124-172 for the 64 paths of a wave: returns throughput x sky colour (0 if the bounce limit
 // ended the path).  The loop leaves as soon as no lane of the wave has a live path.
 template <bool COUNT, bool HOSEK, bool GRID>
+// `cand` / n_cand (GRID builds, lane = pixel): the candidate list of this unit's camera rays (strip_candidates), scanned instead of the
+// grid at bounce 0; n_cand = kNoCand: none.
 MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds& G, bool alive, Rng& rng, f3 ro, f3 rd,
-                          Work<COUNT>& work, uint32_t lane)
+                          Work<COUNT>& work, uint32_t lane, const unsigned short* cand = nullptr, uint32_t n_cand = kNoCand)
 {
     f3 thr = mk(1, 1, 1);
     f3 color = mk(0, 0, 0);
@@ -1237,8 +1303,21 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
         }
         float closest;
         int best;
-        if constexpr (GRID) best = nearest_hit_grid<COUNT>(S, G, ro, rd, alive, closest, work, lane);
-        else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
+        if constexpr (GRID) {
+            if (bounce == 0u && n_cand != kNoCand) {          // wave-uniform: camera rays scan their unit's candidate list
+                closest = kMaxT;
+                best = -1;
+                if (alive) work.add(kCntRays);
+                const float a = dot(rd, rd);
+                const float inv_a = rcp_(a);
+                for (uint32_t j = 0; j < n_cand; ++j) {
+                    const uint32_t id = cand[j];
+                    test_sphere<COUNT>(G.recs[id], id, ro, rd, a, inv_a, alive, closest, best, work);
+                }
+            } else {
+                best = nearest_hit_grid<COUNT>(S, G, ro, rd, alive, closest, work, lane);
+            }
+        } else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
         if (alive) {
             if (best >= 0) {
                 work.add(kCntHits);
@@ -1306,6 +1385,19 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
             Rng rng;
             rng.state = 0;
+            // grid builds: the spheres the camera rays of these 64 pixels can touch (strip_candidates), if the unit lies in one image row
+            uint32_t n_cand = kNoCand;
+            const unsigned short* cand = nullptr;
+            if constexpr (GRID) {
+                unsigned short* my_cand = reinterpret_cast<unsigned short*>(smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, false) + A.grid_bytes) +
+                                          (threadIdx.x >> 6) * (kCandBytes / 2u);
+                const uint32_t unit_x0 = __builtin_amdgcn_readfirstlane(x), unit_n = (AP.out_rows * AP.width - strip * 64u < 64u) ? AP.out_rows * AP.width - strip * 64u : 64u;
+                const uint32_t unit_y = __builtin_amdgcn_readfirstlane(y);
+                if (AP.strip_cand != 0u && unit_x0 + unit_n <= AP.width)
+                    n_cand = strip_candidates(AP, S, unit_x0, unit_n, unit_y, my_cand, lane);
+                n_cand = __builtin_amdgcn_readfirstlane(n_cand);
+                cand = my_cand;
+            }
             for (uint32_t s = 0; s < A.spp; ++s) {
                 f3 ro, rd;
                 {
@@ -1319,7 +1411,7 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
                         generate_primary<false>(A, C, x, y, sample, rng, ro, rd);
                     }
                 }
-                const f3 c = path_radiance<COUNT, HOSEK, GRID>(A, S, G, inside, rng, ro, rd, work, lane);
+                const f3 c = path_radiance<COUNT, HOSEK, GRID>(A, S, G, inside, rng, ro, rd, work, lane, cand, n_cand);
                 acc_r += to_fixed(c.x);
                 acc_g += to_fixed(c.y);
                 acc_b += to_fixed(c.z);
@@ -1374,70 +1466,6 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
         }
         work.flush(A.counters, lane);
     }
-}
-
-// Grid builds: the camera rays of one strip -- up to 16 pixels x spp samples, 39 % of all rays of the RTIOW scene -- leave a lens of a
-// few centimetres through a footprint of a few pixels on the focal plane: one thin bundle.  The wave therefore selects, ONCE per strip, the
-// spheres that bundle can touch (strip_candidates below: a conservative bound, a superset is all that is needed), and the primary rays of
-// the strip scan that short list -- typically the ground and two or three spheres -- instead of paying the always-tested big spheres, the
-// clip, the grid entry and a walk of 4-5 cells each (camera rays graze the slab of small spheres: they are the longest walkers).  The
-// nearest hit over a superset of the spheres a ray can hit is the nearest hit over all spheres, test by test the same arithmetic
-// (test_sphere) and tie-break: identical images.  More than kMaxCand candidates, a strip that wraps into the next row or a bundle that is
-// not thin: the strip's camera rays take the grid like every other ray.
-constexpr uint32_t kMaxCand = 16, kNoCand = 0xffffffffu;
-constexpr uint32_t kCandBytes = 48;       // u16 ids [kMaxCand] | u32 count (kNoCand: use the grid) | pad
-
-// The candidate list of a strip's camera rays (see above).  Pixels [x0, x0 + n) of image row y; all lanes take part.
-// A camera ray (wgsl:456-478) starts at O = eye + e, |e| <= R (the lens), and aims at a point F of the strip's footprint on the
-// focal plane, |F - Fc| <= delta (Fc its centre): P(t) = O + t (F - O) = eye + t (Fc - eye) + w with |w| <= t (delta + R) + R.
-// With a = Fc - eye, D = |a|, and for a sphere (c, r): s = (c - eye) . a / D, d = distance of c from the axis.  A hit needs
-// |c - P(t)| <= r for some t >= 0, hence |s - t D| <= r + R + t g and d <= r + R + t g with g = delta + R; the first gives
-// t <= tmax = (s + r + R) / (D - g) (and s + r + R >= 0), the second then d <= r + R + tmax g.  Everything is evaluated with slack
-// (2 % on g, 5 % + 0.01 + 0.001 |c - eye| on the bound) that dwarfs the rounding of these few float operations, and every
-// comparison is written so that a NaN keeps the sphere: the list is a superset by construction.
-MIRT_DEV uint32_t strip_candidates(const RenderArgs& AP, const SceneLds& S, uint32_t x0, uint32_t n, uint32_t y, unsigned short* ids, uint32_t lane)
-{
-    const f3 eye = mk(S.cam[0], S.cam[1], S.cam[2]), hor = mk(S.cam[4], S.cam[5], S.cam[6]), ver = mk(S.cam[8], S.cam[9], S.cam[10]);
-    const f3 cam_u = mk(S.cam[12], S.cam[13], S.cam[14]), cam_v = mk(S.cam[16], S.cam[17], S.cam[18]), llc = mk(S.cam[20], S.cam[21], S.cam[22]);
-    const float lens_radius = S.cam[19];
-    const float inv_w = 1.0f / (float)AP.width, inv_h = 1.0f / (float)AP.height;
-    const float u0 = (float)x0 * inv_w, u1 = (float)(x0 + n) * inv_w;
-    const float v1 = 1.0f - (float)y * inv_h, v0 = 1.0f - (float)(y + 1u) * inv_h;
-    const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1), du = 0.5f * (u1 - u0), dv = 0.5f * (v1 - v0);
-    const f3 axis = fma3(vc, ver, fma3(uc, hor, llc)) - eye;
-    const float D = __builtin_sqrtf(dot(axis, axis));
-    const float delta = abs_(du) * __builtin_sqrtf(dot(hor, hor)) + abs_(dv) * __builtin_sqrtf(dot(ver, ver));     // triangle inequality over the corners
-    const float R = 1.5f * abs_(lens_radius) * max_(__builtin_sqrtf(dot(cam_u, cam_u)), __builtin_sqrtf(dot(cam_v, cam_v)));
-    const float g = 1.02f * (delta + R) + 1.0e-6f * D;
-    if (!(D > 0.0f && D < 1.0e30f && g < 0.25f * D)) return kNoCand;          // not a thin bundle (or NaN): no list
-    const float inv_D = 1.0f / D;
-    const f3 ah = inv_D * axis;
-    const float inv_den = 1.0f / (D - g);
-    uint32_t count = 0;
-    for (uint32_t base = 0; base < AP.n_spheres; base += 64u) {
-        const uint32_t i = base + lane;
-        const bool valid = i < AP.n_spheres;
-        const PreparedSphere sp = AP.spheres[valid ? i : 0u];
-        const f3 q = mk(sp.cx, sp.cy, sp.cz) - eye;
-        const float r = abs_(sp.radius);
-        const float s = dot(q, ah), qq = dot(q, q);
-        const float d2 = qq - s * s;
-        const float dperp = __builtin_sqrtf(d2 > 0.0f ? d2 : 0.0f);
-        const float len_q = __builtin_sqrtf(qq);
-        const float margin = 0.01f + 1.0e-3f * len_q;
-        const float reach = s + r + R;
-        const float tmax = (reach > 0.0f ? reach : 0.0f) * inv_den;
-        const float bound = 1.05f * (r + R + tmax * g) + margin;
-        const bool out = (reach < -margin) | (dperp > bound);                    // false for NaN: the sphere stays
-        const bool cand = valid & !out;
-        const unsigned long long mask = ballot_(cand);
-        const uint32_t more = (uint32_t)__popcll(mask);
-        if (count + more > kMaxCand) return kNoCand;                             // wave-uniform
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (cand) ids[count + rank] = (unsigned short)i;
-        count += more;
-    }
-    return count;
 }
 
 // Shading routines a path can wait for: the five scatter routines of scatterRay (wgsl:174-314), identified by
