@@ -340,6 +340,35 @@ def test_few_samples_per_launch_ragged_frame(gpu_ctx, oracle, spp_per_frame):
     assert_images_equal(gpu_ctx.accum_resolve(mk(spp_per_frame)), oracle.render(sd, mk(3 * spp_per_frame)), "three frames")
 
 
+@pytest.mark.parametrize("groups", [1, 2, 3])
+def test_lane_per_pixel_units_with_sample_groups(oracle, groups, monkeypatch):
+    """The lane-per-pixel strip kernel deals the samples of a unit's pixels to 1 / 2 / 4 groups of lanes (64 / 32 / 16 pixels per
+    unit) when that gives a short launch enough units; MIRT_PX_GROUPS forces a grouping.  Exact integer sums: every grouping gives
+    the oracle's image (ragged frames included) and, through the accumulation buffer, the oracle's sums."""
+    monkeypatch.setenv("MIRT_PX_GROUPS", str(groups))
+    ctx = m.Context(0)
+    try:
+        for scene, w, h, spp, flags in (("single_sphere", 200, 37, 48, 0), ("three_spheres", 131, 23, 32, m.MIRT_FLAG_KERNEL_STRIP),
+                                        ("single_sphere", 64, 2, 8, 0), ("rtiow_final", 96, 20, 8, 0)):
+            sd = scene_data(scene, w, h)
+            ctx.set_scene(sd)
+            p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=flags)
+            got = ctx.render(p)
+            assert ctx.last_kernel().endswith(",true>") and "strip" in ctx.last_kernel(), ctx.last_kernel()
+            assert_images_equal(got, oracle.render(sd, p), f"{scene} {w}x{h} spp {spp}, {1 << (groups - 1)} sample groups")
+        # progressive accumulation through the same kernel: two adds of 16 samples == the oracle's sums of 32
+        sd = scene_data("three_spheres", 70, 9)
+        ctx.set_scene(sd)
+        p16 = m.make_params(70, 9, 16, mode=m.MIRT_MODE_PT, num_bounces=6, flags=m.MIRT_FLAG_KERNEL_STRIP)
+        ctx.accum_reset(p16)
+        ctx.accum_add(p16)
+        ctx.accum_add(p16)
+        want = oracle.render_pt_sums(sd, m.make_params(70, 9, 32, mode=m.MIRT_MODE_PT, num_bounces=6))
+        assert np.array_equal(ctx.accum_read(p16), want)
+    finally:
+        ctx.close()
+
+
 def test_raytracer_render_frame_progression(oracle):
     """The reference's progressive loop (mod.rs:626-670): N spp per frame until max, then frames stop adding."""
     scene, cam = m.scenes.three_spheres()
@@ -572,7 +601,7 @@ def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
 
 def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
     """mirt_kernels.h kPoolMinSpp*: several shading routines -> pool from 40 spp; one routine -> lane-per-pixel strip kernel below
-    184 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
+    304 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
     choice renders the same image as the forced alternatives (checked throughout this file); here: the names."""
     def kernel(scene, w, h, spp):
         gpu_ctx.set_scene(scene_data(scene, w, h))
@@ -581,8 +610,8 @@ def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
     assert kernel("three_spheres", 640, 360, 36) == "render_pt_strip_kernel<false,false,false,true>"
     assert kernel("three_spheres", 640, 360, 40).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 640, 360, 100) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 176) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 184).startswith("render_pt_pool_kernel<256,112,6,")
+    assert kernel("single_sphere", 640, 360, 296) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("single_sphere", 640, 360, 304).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 64, 36, 100) == "render_pt_strip_kernel<false,false,false,false>"      # tiny frame: lanes on samples
     assert kernel("rtiow_final", 640, 360, 12) == "render_pt_strip_kernel<false,false,true,true>"
     assert kernel("rtiow_final", 640, 360, 16).startswith("render_pt_pool_kernel<1024,")

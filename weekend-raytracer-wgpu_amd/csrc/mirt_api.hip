@@ -205,6 +205,8 @@ struct Tuning {
     double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
     double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
     int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
+    int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed / dealt round-robin (A/B runs)
+    int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
 };
 
@@ -220,6 +222,8 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
     if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
     if (const char* e = std::getenv("MIRT_PINHOLE")) t.pinhole = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_STATIC_UNITS")) t.static_units = (e[0] == '1') ? 1 : 0;
+    if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
@@ -708,7 +712,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
     // pools still leave >= 16 waves per CU resident beside the scene tables; the sample counts from which it does are
     // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 40 for scenes
-    // with several shading routines, 184 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
+    // with several shading routines, 304 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
     // beat: single metal sphere, 1080p x 100 spp, 1.38 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
     // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
@@ -821,12 +825,28 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // parity mode at the reference's operating point (2 samples per pixel, mod.rs:605-613): lane = pixel as well, counting or not
     if (!pt) by_pixel = (p->flags & MIRT_FLAG_KERNEL_STRIP) ? false : (tune.by_pixel >= 0 ? tune.by_pixel == 1 : p->spp < mirt::kByPixelMaxSpp);
     a.static_units = 0;
+    a.px_groups_log2 = 0;
     if (by_pixel) {
-        a.n_units = (uint32_t)((npix + 63u) / 64u);
+        // Path-traced lane-per-pixel units: 64 pixels x all samples -- or 32 / 16 pixels with the samples dealt to 2 / 4 groups of lanes:
+        // smaller units are more units, and the last unit of a wave is then a smaller part of its life (config 2, 1080p x 100 spp, had 4
+        // units per wave: 1.21 -> 0.98 ms with 32-pixel units).  Measured limits (tools/ab_libs.py, MIRT_PX_GROUPS): every group keeps
+        // >= 16 samples (1080p, three spheres: 32 spp -9 % with two groups, 16 spp +13 %), and the launch stays below ~65 000 units -- one
+        // dispenser atomic per unit serialises on its address (1080p x 100 spp with 16-pixel units, 129 600 of them: 1.49 ms; an
+        // 800x600 frame of the same scene, 30 000 units: 0.70 -> 0.39 ms).  Never with the reference's per-frame stream, whose samples
+        // are sequentially dependent; the samples must divide evenly.
+        if (pt && !frame_stream && tune.px_groups != 0) {
+            const uint64_t max_units = 8ull * (uint64_t)c->cu_count * 32u;
+            while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= 16u &&
+                   ((npix << (a.px_groups_log2 + 1u)) + 63u) / 64u <= max_units)
+                a.px_groups_log2 += 1u;
+            if (tune.px_groups > 0 && p->spp % (1u << (tune.px_groups - 1)) == 0u) a.px_groups_log2 = (uint32_t)tune.px_groups - 1u;
+        }
+        a.n_units = (uint32_t)((npix + (64u >> a.px_groups_log2) - 1u) / (64u >> a.px_groups_log2));
         // units dealt round-robin instead of dispensed: path-traced mode below 8 spp (measured crossover, tools/low_spp.py); parity mode
         // always -- its lane = pixel units are a few dozen sphere tests each, and one dispenser atomic per unit (14 ns, serialised on
         // its address) was the whole kernel time: 7 500 units of an 800x600 frame at 2 spp 94 us whatever the work
         a.static_units = (!pt || p->spp < 8u) ? 1u : 0u;
+        if (tune.static_units >= 0) a.static_units = (uint32_t)tune.static_units;
     }
 
     uint32_t blocks;

@@ -106,11 +106,12 @@ constexpr uint32_t kGridPoolSlotChoices[4] = { 160, 152, 128, 96 };   // the lar
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
 //   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40
-//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): strip 1.38 / 2.44 / 2.67 / 2.86 ms at
-//   100 / 176 / 192 / 208 spp, pool 1.82 / 2.49 / 2.63 / 2.76                                                          -> 184
+//   (round 3, two sample groups from 32 spp on: strip 1.37 / 1.65 / 1.96 ms at 32 / 40 / 48 spp, pool 1.55 / 1.65 / 1.76: still 40)
+//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose; round 3, 32-pixel units with two sample groups): strip
+//   1.06 / 2.05 / 4.05 / 9.59 ms at 100 / 200 / 400 / 1000 spp, pool 1.81 / 2.39 / 3.77 / 7.98                      -> 304
 //   many-sphere scenes (grid build, RTIOW): strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66   -> 16
 constexpr uint32_t kPoolMinSpp           = 40;
-constexpr uint32_t kPoolMinSppOneRoutine = 184;
+constexpr uint32_t kPoolMinSppOneRoutine = 304;
 constexpr uint32_t kPoolMinSppGrid       = 16;
 
 enum CounterSlot : uint32_t {
@@ -150,6 +151,7 @@ struct RenderArgs {
     uint32_t out_rows;                     // rows this launch writes
     uint32_t n_units;                      // work units (strips) the dispenser hands out
     uint32_t static_units;                 // lane-per-pixel strip kernel: units dealt round-robin instead of dispensed
+    uint32_t px_groups_log2;               // lane-per-pixel strip kernel: a unit is 64 >> g pixels, their samples dealt to 1 << g groups of lanes
     // pool kernel, guided self-scheduling: level l = strips of (kStripPixels >> l) pixels; it starts at unit
     // lvl_unit[l] / pixel lvl_pix[l] (entry kStripLevels = end).  Strips shrink 16 -> 1 pixels towards the end of
     // the frame so that all waves finish within a fraction of a strip of each other.

@@ -11,7 +11,7 @@
 //   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
 //                          paths in LDS, queued by the shading routine they wait for, and always
 //                          runs ONE routine on up to 64 of them — the material switch no longer
-//                          serialises inside a wave (default from 40 / 184 / 16 samples per pixel on for scenes
+//                          serialises inside a wave (default from 40 / 304 / 16 samples per pixel on for scenes
 //                          with several / one shading routine / many spheres: mirt_kernels.h, kPoolMinSpp*).
 //
 // Every pixel's radiance is summed in 64-bit fixed point (exact, order-independent), so the three
@@ -1371,41 +1371,53 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
     // the waves of the grid (A.static_units): one dispenser atomic per unit serialises on its address (measured:
     // 14 ns each, 0.47 ms for the 32 400 units of a 1080p frame whatever the work) and the units are alike.
     const uint32_t grid_waves = gridDim.x * (kBlockThreads / 64u);
+    // (Dispensing these units in batches -- a static first batch per wave, then guided batches of (units left) / (waves) per atomic -- was
+    //  measured: 16 ... 110 % SLOWER than one unit per atomic at every unit size; the dispenser is a limit only beyond ~65 000 units per launch.)
     for (uint32_t strip = first_unit(); strip < A.n_units;
          strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit(A, lane)) {
         if constexpr (BY_PIXEL) {
             // arguments needed once per unit are read from the kernarg segment here and now (per_strip_args) instead of
             // living in SGPRs across the sample loop, which the 8-waves-per-SIMD build has too few of
             const RenderArgs& AP = per_strip_args();
-            const uint32_t pi = strip * 64u + lane;
+            // A unit is 64 >> g pixels x all samples, its samples dealt to 1 << g groups of lanes (AP.px_groups_log2, chosen on the
+            // host): units of a quarter of the pixels are four times as many, so that the waves of a short launch -- config 2 lasts
+            // 1.2 ms and had 4 units per wave, each a quarter of a wave's life -- finish within a small fraction of each other.  The sums
+            // are exact integers: any split of a pixel's samples over lanes gives the same total.
+            const uint32_t g = AP.px_groups_log2;
+            const uint32_t unit_px = 64u >> g;
+            const uint32_t grp = lane >> (6u - g);               // which share of the samples this lane takes
+            const uint32_t pi = strip * unit_px + (lane & (unit_px - 1u));
             const bool inside = pi < AP.out_rows * AP.width;
             const uint32_t ci = (inside ? pi : 0u) / AP.width;
             const uint32_t x = (inside ? pi : 0u) - ci * AP.width;
             const uint32_t y = abs_row(AP, ci);
+            const uint32_t n_mine = AP.spp >> g;                 // wave-uniform: the host deals shares only when they are equal (spp % (1 << g) == 0)
+            const uint32_t s_first = AP.sample_begin + grp * n_mine;
             unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
             Rng rng;
             rng.state = 0;
-            // grid builds: the spheres the camera rays of these 64 pixels can touch (strip_candidates), if the unit lies in one image row
+            // grid builds: the spheres the camera rays of these pixels can touch (strip_candidates), if the unit lies in one image row
             uint32_t n_cand = kNoCand;
             const unsigned short* cand = nullptr;
             if constexpr (GRID) {
                 unsigned short* my_cand = reinterpret_cast<unsigned short*>(smem + scene_lds_bytes_dev(A.n_spheres, A.n_mats, HOSEK, false) + A.grid_bytes) +
                                           (threadIdx.x >> 6) * (kCandBytes / 2u);
-                const uint32_t unit_x0 = __builtin_amdgcn_readfirstlane(x), unit_n = (AP.out_rows * AP.width - strip * 64u < 64u) ? AP.out_rows * AP.width - strip * 64u : 64u;
+                const uint32_t left = AP.out_rows * AP.width - strip * unit_px;
+                const uint32_t unit_x0 = __builtin_amdgcn_readfirstlane(x), unit_n = left < unit_px ? left : unit_px;
                 const uint32_t unit_y = __builtin_amdgcn_readfirstlane(y);
                 if (AP.strip_cand != 0u && unit_x0 + unit_n <= AP.width)
                     n_cand = strip_candidates(AP, S, unit_x0, unit_n, unit_y, my_cand, lane);
                 n_cand = __builtin_amdgcn_readfirstlane(n_cand);
                 cand = my_cand;
             }
-            for (uint32_t s = 0; s < A.spp; ++s) {
+            for (uint32_t j = 0; j < n_mine; ++j) {
                 f3 ro, rd;
                 {
                     const CamRegs C = load_camera(S, A);
-                    const uint32_t sample = A.sample_begin + s;
+                    const uint32_t sample = s_first + j;
                     if (A.frame_spp == 0u) {
                         generate_primary(A, C, x, y, sample, rng, ro, rd);
-                    } else {                     // the reference's stream: frame = sample / n + 1 seeds once, its n samples share it
+                    } else {                     // the reference's stream: frame = sample / n + 1 seeds once, its n samples share it (g == 0)
                         if (sample % A.frame_spp == 0u)
                             rng.state = jenkins_hash(((x + y * A.width) ^ jenkins_hash(sample / A.frame_spp + 1u)) ^ A.seed_mix);
                         generate_primary<false>(A, C, x, y, sample, rng, ro, rd);
@@ -1416,7 +1428,12 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
                 acc_g += to_fixed(c.y);
                 acc_b += to_fixed(c.z);
             }
-            if (inside) {
+            for (uint32_t off = unit_px; off < 64u; off <<= 1) {                 // add the shares: lanes l, l + unit_px, ... hold one pixel
+                acc_r += __shfl_xor(acc_r, (int)off, 64);
+                acc_g += __shfl_xor(acc_g, (int)off, 64);
+                acc_b += __shfl_xor(acc_b, (int)off, 64);
+            }
+            if (inside && grp == 0u) {
                 const RenderArgs& AS = per_strip_args();
                 if (AS.accum) {                  // progressive mode: add the exact sums, resolve later
                     AS.accum[3ull * pi + 0] += acc_r; AS.accum[3ull * pi + 1] += acc_g; AS.accum[3ull * pi + 2] += acc_b;
