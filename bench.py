@@ -342,7 +342,7 @@ def steady_state_line(m, torch, ctx, base, w: int, h: int, spp: int = 1000, laun
     tf = flops / (ms * 1e-3) / 1e12
     return {"spp": spp, "kernel": kernel, "kernel_ms_avg": round(ms, 4), "value_from_kernel_time": round(w * h * spp / ms / 1e3, 2),
             "unit": "Msamples/s", "roofline_frac": round(tf / PEAK_FP32_VECTOR_TFLOPS, 4),
-            "note": "same scene and frame at 1000 spp, outside the timed region: the rate without the ramp-up and tail of a 1.4 ms launch"}
+            "note": "same scene and frame at 1000 spp, outside the timed region: the rate without the ramp-up and tail of a 1 ms launch"}
 
 
 def parity_schedules_line(m, torch, ctx, base, w: int, h: int, launches: int = 20) -> dict:
