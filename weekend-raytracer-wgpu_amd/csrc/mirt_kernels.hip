@@ -1226,6 +1226,9 @@ MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, ui
 // (test_sphere) and tie-break: identical images.  More than kMaxCand candidates, a strip that wraps into the next row or a bundle that is
 // not thin: the strip's camera rays take the grid like every other ray.
 constexpr uint32_t kMaxCand = 16, kNoCand = 0xffffffffu;
+// (Flat scenes -- a handful of spheres, no grid -- were given the lists too, so that a strip that sees only the ground tests one sphere and a
+//  sky strip none: measured +2.5 % on config 3 and +2 % on config 4, whose three / two sphere records already sit in scalar registers;
+//  -1.7 % on the five-sphere main.rs scene.  Removed: profiles/r03_flat_ab.txt block 7.)
 constexpr uint32_t kCandBytes = 48;       // u16 ids [kMaxCand] | u32 count (kNoCand: use the grid) | pad
 
 // The candidate list of a strip's camera rays (see above).  Pixels [x0, x0 + n) of image row y; all lanes take part.
