@@ -877,7 +877,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
     const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
+    if (!(by_pixel && a.static_units))           // units dealt round-robin never touch the dispenser: one memset node less per interactive frame
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
 #endif
