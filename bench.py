@@ -470,6 +470,23 @@ class PatternContext:
 # launcher: N > 1 from a bare shell
 # ------------------------------------------------------------------------------------------------
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator comes up; rank 0's stdout is reserved for the ONE JSON line.  File
+    descriptor 1 points at stderr while the process group and its first collective are set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -508,6 +525,9 @@ def parse_args(argv):
                                                         "BASELINE configs[4] in full); the workload string says so")
     ap.add_argument("--size", default="", help="override the config's frame, WxH (e.g. --config parity --size 800x600 --spp 2 = the "
                                                "reference's own operating point, main.rs:28 / mod.rs:605-613); the workload string says so")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with --gpus 1: form a ONE-rank process group (RCCL; gloo with --dry-run) and take every N > 1 branch -- gather, "
+                         "all-reduces, barriers, gather_ms, verification of the gathered frame -- on a box with a single GPU; measures nothing new")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank path on CPU (gloo, pattern renderer); measures nothing")
     return ap.parse_args(argv)
 
@@ -539,12 +559,21 @@ def main(argv=None) -> int:
         return err[0]
     if not dry:
         torch.cuda.set_device(local_rank)                                 # one rank per GPU
+    multi = world > 1 or args.rehearse_collectives            # the code below takes its N > 1 branches
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():
+            if dry:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif multi:                                                # a one-rank group of its own
+        init = f"tcp://127.0.0.1:{free_port()}"
+        with stdout_to_stderr():
+            if dry:
+                dist.init_process_group(backend="gloo", init_method=init, rank=0, world_size=1)
+            else:
+                dist.init_process_group(backend="nccl", init_method=init, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     import weekend_raytracer_wgpu_amd as m
 
@@ -577,23 +606,32 @@ def main(argv=None) -> int:
     base = base_params(m, cfg, flags=int(os.environ.get("MIRT_BENCH_FLAGS", "0"), 0))   # e.g. 0x10 strip / 0x20 pool (A/B runs)
     # N > 1: the gather of frame i overlaps the render of frame i+1 (double-buffered parts, async collective);
     # every frame is complete on rank 0 before the timed region ends (flush).  MIRT_BENCH_PIPELINE=0: one frame at a time.
-    pipelined = world > 1 and os.environ.get("MIRT_BENCH_PIPELINE", "1") != "0"
-    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined, device=device)
+    pipelined = multi and os.environ.get("MIRT_BENCH_PIPELINE", "1") != "0"
+    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined, device=device,
+                                   _rehearse_single_rank=multi and world == 1)
+
+    def gather_now():
+        """ONE gather of the current part buffers to rank 0 (the rehearsal's one-rank group included)."""
+        if world == 1:
+            dist.gather(frame.local, list(frame.parts.unbind(0)), dst=0)
+            return frame.parts
+        return m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
 
     def sync():
         if not dry:
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
-    if world > 1:
+    if multi:
         # communicator set-up, not a step: RCCL opens its point-to-point channels on first use, so push one
         # gather of the (still empty) buffers through before anything is timed
-        m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
-        sync()
-        barrier()
+        with stdout_to_stderr():
+            gather_now()
+            sync()
+            barrier()
 
     for _ in range(args.warmup):
         frame.step()
@@ -612,7 +650,7 @@ def main(argv=None) -> int:
     st = ctx.stats()                                    # HIP-event time of the K kernels of the timed region
     kernel_ms = st["kernel_ms_total"] / max(1, st["launches"])
     red_dev = torch.device("cpu") if dry else torch.device("cuda")
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -624,7 +662,7 @@ def main(argv=None) -> int:
     else:
         kernel_ms_max = kernel_ms
         kernel_ms_per_rank = [round(kernel_ms, 4)]
-    partition = ("whole frame" if world == 1 else
+    partition = ("whole frame" if not multi else
                  f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather per frame"
                  + (" (overlapping the next frame's render)" if pipelined else ""))
     total_samples = w * h * spp
@@ -632,13 +670,13 @@ def main(argv=None) -> int:
     # N > 1: one gather + de-interleave on its own, after the clock has stopped (the timed region overlaps it with the next
     # frame's render, so it cannot be read off the step time): rank 0's wall time of [gather, assemble], ranks released together
     gather_ms = None
-    if world > 1:
+    if multi:
         reps, acc = 5, 0.0
         for _ in range(reps):
             barrier()
             sync()
             tg = time.perf_counter()
-            parts = m.multi_gpu.gather_parts(frame.local, rank, world, dst=0, out=frame.parts)
+            parts = gather_now()
             if rank == 0:
                 frame._assemble(parts, frame._stream())
             sync()
@@ -655,12 +693,12 @@ def main(argv=None) -> int:
             rows = verify_rows(m, None, cfg, got, oracle_rows=lambda first, last: pattern_rows(range(first, last), w))
             ok = ok and all(r.get("equal") for r in rows)
             print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "frames_verified": ok, "verified_rows": rows, "verified_frame": "gathered on rank 0" if world > 1 else "whole frame",
-                              "gather_ms": gather_ms, "launches_rank0": st["launches"], "backend": "gloo" if world > 1 else "none",
+                              "frames_verified": ok, "verified_rows": rows, "verified_frame": "gathered on rank 0" if multi else "whole frame",
+                              "gather_ms": gather_ms, "launches_rank0": st["launches"], "backend": "gloo" if multi else "none",
                               "kernel_ms_per_rank": kernel_ms_per_rank,
                               "config": {"workload": f"DRY RUN ({w}x{h} pattern frame, no GPU, nothing measured)", "partition": partition}}),
                   flush=True)
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return 0 if ok else 4
@@ -671,21 +709,21 @@ def main(argv=None) -> int:
     uses_grid = kernel_uses_grid(kernel_name)
     pc = m.multi_gpu.part_params(base, rank, world, args.tile_rows)
     pc.flags |= m.MIRT_FLAG_COUNT_WORK | (m.MIRT_FLAG_COUNT_GRID if uses_grid else 0)
-    scratch = torch.empty((frame.max_rows if world > 1 else frame.frame.shape[0], w, 4), dtype=torch.uint8, device=device)
+    scratch = torch.empty((frame.max_rows if multi else frame.frame.shape[0], w, 4), dtype=torch.uint8, device=device)
     ctx.render_device(pc, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     work = ctx.stats()
     counting_kernel = ctx.last_kernel()
     flops = algorithmic_flops(work, mode=cfg["mode"], grid=uses_grid)      # of THIS rank's share
     flops_all = flops
-    if world > 1:
+    if multi:
         t = torch.tensor([flops], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         flops_all = float(t.item())
 
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
-        traffic = profiled_traffic(kernel_name, cfg["workload"]) if world == 1 else None
+        traffic = profiled_traffic(kernel_name, cfg["workload"]) if not multi else None
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
         out_bytes = frame.rows * w * 4
         algo_bytes = algorithmic_bytes(sd, cfg["mode"], out_bytes)
@@ -718,7 +756,7 @@ def main(argv=None) -> int:
                 "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
                 "valu_busy_pct_profiled": (round(traffic[2], 1) if traffic and traffic[2] is not None else None),
                 "valu_lane_utilization_pct_profiled": (round(traffic[3], 1) if traffic and traffic[3] is not None else None),
-                "scope": "whole frame" if world == 1 else f"rank 0's share (its tiles: {frame.rows} of {h} rows); achieved_whole_job = all ranks' flops / slowest rank's kernel time",
+                "scope": "whole frame" if not multi else f"rank 0's share (its tiles: {frame.rows} of {h} rows); achieved_whole_job = all ranks' flops / slowest rank's kernel time",
                 "achieved_whole_job": round(flops_all / (kernel_ms_max * 1e-3) / 1e12, 3),
                 "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
@@ -740,19 +778,19 @@ def main(argv=None) -> int:
                         "rocprofv3 summaries under profiles/",
             },
         }
-        if world == 1 and cfg["mode"] == "pt":
+        if not multi and cfg["mode"] == "pt":
             result["fast_math"] = fast_math_line(m, torch, ctx, base, frame.frame, total_samples, flops)
             if args.config == "4":
                 result["texel_tiles"] = texel_tiles_line(m, torch, ctx, base, frame.frame, total_samples)
             if args.config == "2":
                 result["steady_state"] = steady_state_line(m, torch, ctx, base, w, h)
-        if world == 1 and cfg["mode"] == "parity":
+        if not multi and cfg["mode"] == "parity":
             result["parity_schedules"] = parity_schedules_line(m, torch, ctx, base, w, h)
-        if world > 1:
+        if multi:
             result["gather_ms"] = gather_ms
             result["gather_note"] = "one gather + de-interleave alone on rank 0 (no render), after the timed region; the timed steps overlap it with the next frame's render"
         cpu_rate = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, sd, cfg)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
             cpu_rate = result["cpu_baseline"]["value"] if cfg["mode"] == "pt" else None
@@ -763,11 +801,11 @@ def main(argv=None) -> int:
         if not args.no_cpu_baseline:
             # the frame the timed region left on rank 0 -- for N > 1 the one gathered over RCCL -- against oracle rows
             result["verified_rows"] = verify_rows(m, sd, cfg, frame.frame.cpu().numpy(), cpu_msamples_per_s=cpu_rate)
-            result["verified_frame"] = "whole frame" if world == 1 else f"gathered from {world} ranks on rank 0"
+            result["verified_frame"] = "whole frame" if not multi else f"gathered from {world} rank{'s' if world > 1 else ' (rehearsal: a one-rank group)'} on rank 0"
         print(json.dumps(result), flush=True)
 
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -143,3 +143,14 @@ def test_kernel_schedule_names():
     assert bench.kernel_schedule("render_pt_strip_kernel<true,false,false,false>") == "strip/sample"
     assert bench.kernel_schedule("render_pt_pool_kernel<256,112,6,false,false,3,false>") == bench.kernel_schedule("render_pt_pool_kernel<256,112,1,true,false,5,false>") == "pool"
     assert bench.kernel_schedule("render_parity_kernel<false,true>") == "parity/pixel" != bench.kernel_schedule("render_parity_kernel<true,false>")
+
+
+def test_the_rehearsal_of_the_n_rank_branches_runs_without_a_gpu():
+    """`bench.py --rehearse-collectives --dry-run`: a one-rank gloo group through every N > 1 branch (the GPU suite runs the same
+    over RCCL)."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run", "--rehearse-collectives", "--steps", "2", "--warmup", "1"],
+                       env=_bare_env(), capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["frames_verified"] and d["verified_frame"] == "gathered on rank 0" and d["backend"] == "gloo" and d["gather_ms"] > 0.0

@@ -17,8 +17,8 @@ CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def _bench(*args):
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]          # stdout is the ONE JSON line, nothing else (no RCCL banner)
     return json.loads(lines[0])
 
 
@@ -54,3 +54,16 @@ def test_config4_line_reports_the_texel_tile_build():
     t = d["texel_tiles"]
     assert t["kernel"].startswith("render_pt_pool_tile_kernel<256,") and t["frame_identical_to_default_build"] is True
     assert t["tile_hit_rate_pct"]["camera_ray_hits"] > 50.0 > t["tile_hit_rate_pct"]["later_bounces"]
+
+
+def test_the_n_rank_branches_run_over_rccl_on_one_gpu():
+    """`--rehearse-collectives`: a ONE-rank RCCL group, and every branch an N > 1 run takes -- tiled frame with the pipelined async
+    gather, the all-reduces of elapsed time / kernel times / flops, gather_ms, verification of the GATHERED frame against oracle rows,
+    barrier and teardown.  The driver's 2 / 4 / 8-GPU runs execute exactly this code with more ranks."""
+    d = _bench("--config", "2", "--rehearse-collectives", "--steps", "3", "--warmup", "1")
+    assert CONTRACT <= set(d) and d["n_gpus"] == 1
+    assert "gather per frame" in d["config"]["partition"] and "overlapping" in d["config"]["partition"]
+    assert d["gather_ms"] > 0.0 and d["verified_frame"].startswith("gathered from 1 rank")
+    assert len(d["verified_rows"]) >= 4 and all(v["equal"] for v in d["verified_rows"])
+    assert d["roofline"]["scope"].startswith("rank 0's share") and d["roofline"]["achieved_whole_job"] > 0.0
+    assert "cpu_baseline" not in d and len(d["roofline"]["kernel_ms_per_rank"]) == 1
