@@ -179,6 +179,32 @@ def test_hosek_sky_blob(gpu_ctx, oracle):
         assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
 
 
+@pytest.mark.parametrize("kernel,spp", [(m.MIRT_FLAG_KERNEL_POOL, 32), (m.MIRT_FLAG_KERNEL_STRIP, 8), (0, 100)])
+def test_hosek_sky_on_a_many_sphere_scene_and_tile_partitions(gpu_ctx, oracle, kernel, spp):
+    """The Hosek builds of the grid kernels (pool: candidate lists, ShadeRec; strip: lane per pixel with candidate lists) on RTIOW, and
+    the same frame rendered as 3 interleaved tile partitions (absolute rows feed the candidate bound): all equal to the oracle."""
+    w, h = 160, 45
+    sd = scene_data("rtiow_final", w, h)
+    sky = m._abi.MirtSkyState()
+    for c in range(3):
+        for i, v in enumerate([-1.1, -0.3, 0.5, 1.2, -2.5, 0.4, 0.2, 1.5, 0.6]):
+            sky.params[9 * c + i] = v * (1.0 + 0.1 * c)
+        sky.radiances[c] = 1.0 + c
+    sky.sun_direction[:] = [0.0, 0.6, 0.8, 0.0]
+    sd.sky = sky
+    gpu_ctx.set_scene(sd)
+    for flags in (m.MIRT_FLAG_SKY_HOSEK | kernel, kernel):
+        base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=flags)
+        want = oracle.render(sd, base)
+        assert_images_equal(gpu_ctx.render(base), want, f"whole frame, flags {flags:#x}, {gpu_ctx.last_kernel()}")
+        world, tr = 3, 4
+        parts = np.zeros((world, m.multi_gpu.max_part_rows(base, world, tr), w, 4), np.uint8)
+        for r in range(world):
+            img = gpu_ctx.render(m.multi_gpu.part_params(base, r, world, tr))
+            parts[r, :img.shape[0]] = img
+        assert_images_equal(m.multi_gpu.assemble_host(parts, base, world, tr), want, f"3 tile partitions, flags {flags:#x}")
+
+
 def test_missing_material_id_and_every_material(gpu_ctx, oracle):
     """All five scatter branches incl. the pink 'missing material' one (wgsl:309-314), textures > 1x1
     on metal and checker, fuzz 0 and 1, ior < 1."""
