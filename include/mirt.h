@@ -188,12 +188,14 @@ typedef struct MirtParams {
      * wgsl:498-502) and its n samples draw from that one stream in turn (samplePixel, wgsl:105-122), exactly as
      * Raytracer::render_frame advances (mod.rs:303-351, 626-670).  Needs spp % n == 0 and sample_begin % n == 0;
      * runs on the lane-per-pixel schedule (a pixel's samples are then sequentially dependent).  Frame numbers count from
-     * sample 0 of the accumulation: the reference's frame_number survives render_progress.reset() (mod.rs:284, 385), so
-     * only its first accumulation after start-up is reproduced number for number (a caller that wants the later ones
-     * passes sample_begin = n * frames rendered before, to mirt_ctx_render*; mirt_ctx_accum_add always continues at
-     * the samples it holds). */
+     * sample 0 of the accumulation plus `frame_begin` (below): the reference's frame_number survives
+     * render_progress.reset() (mod.rs:284, 385), so accumulations after the first start at a later frame. */
     uint32_t frame_spp;
-    uint32_t _reserved;    /* 0 */
+    /* PT with frame_spp > 0: the frames the reference's Raytracer had rendered BEFORE sample 0 of this accumulation, i.e. its
+     * `frame_number - 1` at the reset -- `frame_number` starts at 1, advances with every render_frame call (completed frames
+     * included) and survives `render_progress.reset()` (mod.rs:284, 350, 385).  Sample s then draws from the stream of frame
+     * frame_begin + s / frame_spp + 1.  0 = a freshly constructed Raytracer.  Ignored when frame_spp == 0. */
+    uint32_t frame_begin;
 } MirtParams;
 
 /* Work counters of the last render on a context (rocprof-independent).  The ray/test/scatter

@@ -431,7 +431,7 @@ int mirt_oracle_render_pt(const MirtScene* scene, const MirtParams* params, uint
                     const uint32_t sample = params->sample_begin + s;
                     if (params->frame_spp) {
                         /* frame f = sample / n + 1 seeds once: rng_init's `sample + 1` is the frame number */
-                        if (sample % params->frame_spp == 0) frame_rng = rng_init(x + y * T.W, sample / params->frame_spp, T.mix);
+                        if (sample % params->frame_spp == 0) frame_rng = rng_init(x + y * T.W, params->frame_begin + sample / params->frame_spp, T.mix);   /* frame_number survives resets: mod.rs:284, 350, 385 */
                         trace_sample(&T, x, y, sample, q, &frame_rng);
                     } else {
                         trace_sample(&T, x, y, sample, q, NULL);

@@ -340,8 +340,10 @@ def _srgb_oetf(x):
 
 
 def render_pt(sc: Scene, width: int, height: int, frames: int, samples_per_frame: int, num_bounces: int = 8, flags: int = 0,
-              rows=None):
-    """`frames` calls of the fragment shader over the rows `rows` (default all), `samples_per_frame` samples each.
+              rows=None, frames_before: int = 0):
+    """`frames` calls of the fragment shader over the rows `rows` (default all), `samples_per_frame` samples each, after
+    `frames_before` earlier calls (frame_number is never reset, mod.rs:284, 350, 385: an accumulation that starts after a camera
+    move begins at a later frame).
     Returns (rgba8 uint8 [len(rows), width, 4], accumulated float32 [len(rows), width, 3] = the shader's imageBuffer)."""
     ys = np.arange(height, dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
     X, Y = np.meshgrid(np.arange(width, dtype=np.int64), ys)
@@ -353,7 +355,7 @@ def render_pt(sc: Scene, width: int, height: int, frames: int, samples_per_frame
     pixel = [np.zeros(n_px, f32) for _ in range(3)]           # imageBuffer[idx], cleared on the first frame
     hosek = bool(flags & FLAG_SKY_HOSEK)
     with np.errstate(all="ignore"):
-        for frame in range(1, frames + 1):                    # frame_number starts at 1 (mod.rs:284)
+        for frame in range(frames_before + 1, frames_before + frames + 1):      # frame_number starts at 1 (mod.rs:284) and never resets
             rng = init_rng(X, Y, width, frame)
             color = [np.zeros(n_px, f32) for _ in range(3)]
             for _s in range(samples_per_frame):               # samplePixel

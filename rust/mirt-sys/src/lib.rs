@@ -145,7 +145,7 @@ pub struct MirtParams {
     pub part: u32,
     pub sample_begin: u32,
     pub frame_spp: u32,
-    pub _reserved: u32,
+    pub frame_begin: u32,
 }
 
 #[repr(C)]

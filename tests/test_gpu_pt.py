@@ -557,6 +557,14 @@ def test_reference_frame_stream_vs_oracle(gpu_ctx, oracle, scene, w, h, spp, n):
     assert np.array_equal(gpu_ctx.accum_read(p1), oracle.render_pt_sums(sd, whole))
     if n > 1:
         assert not np.array_equal(gpu_ctx.render(whole), gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)))
+    # an accumulation that starts at a later frame (MirtParams.frame_begin: the reference's frame_number is never reset)
+    later = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=n, frame_begin=11)
+    assert_images_equal(gpu_ctx.render(later), oracle.render(sd, later), f"{scene} frame_begin 11")
+    gpu_ctx.accum_reset(later)
+    l1 = m.make_params(w, h, n, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=n, frame_begin=11)
+    for _ in range(spp // n):
+        gpu_ctx.accum_add(l1)
+    assert np.array_equal(gpu_ctx.accum_read(l1), oracle.render_pt_sums(sd, later))
 
 
 def test_frame_stream_param_errors(gpu_ctx, oracle):
@@ -598,6 +606,16 @@ def test_raytracer_render_frame_with_the_reference_stream(oracle):
     for k in (2, 4, 6, 8, 8):
         img = rt.render_frame()
         assert_images_equal(img, oracle.render(sd, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2)), f"after {k} spp")
+    assert rt.frame_number == 6                      # five render_frame calls, the idle one (accumulation complete) included: mod.rs:350
+    # a camera move resets the accumulation (mod.rs:385) but NOT the frame number: the new accumulation's frames are 6, 7, ...
+    cam2 = m.Camera(cam.eye_pos + np.float32([0.5, 0.0, 0.0]), cam.eye_dir, cam.up, cam.vfov, cam.aperture, cam.focus_distance)
+    rt.set_render_params(m.RenderParams(camera=cam2, viewport_size=(64, 40), sampling=m.SamplingParams(8, 2, 8)))
+    sd2 = rt.scene_data()
+    for k in (2, 4):
+        img = rt.render_frame()
+        want = oracle.render(sd2, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2, frame_begin=5))
+        assert_images_equal(img, want, f"after the camera move, {k} spp")
+    assert rt.frame_number == 8
     rt.close()
 
 

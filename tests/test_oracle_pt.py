@@ -151,6 +151,20 @@ def test_frame_stream_first_sample_is_the_wgsl_frame_stream(oracle):
     assert (f2_first >= f2_rest).all() and (f2_first != f2_rest).any()
 
 
+def test_frame_begin_shifts_the_frame_numbers(oracle):
+    """frame_begin = k: sample s draws from the stream of frame k + s / n + 1 -- the same streams as an accumulation that began at
+    frame 1 and is k frames in (sample_begin = k n), so the two calls must give the same sums; k = 0 is the old behaviour."""
+    w, h, n, k = 24, 16, 3, 5
+    sd = scene_data("three_spheres", w, h)
+    shifted = oracle.render_pt_sums(sd, m.make_params(w, h, 2 * n, mode=m.MIRT_MODE_PT, frame_spp=n, frame_begin=k))
+    later = oracle.render_pt_sums(sd, m.make_params(w, h, 2 * n, mode=m.MIRT_MODE_PT, frame_spp=n, sample_begin=k * n))
+    first = oracle.render_pt_sums(sd, m.make_params(w, h, 2 * n, mode=m.MIRT_MODE_PT, frame_spp=n))
+    assert np.array_equal(shifted, later) and not np.array_equal(shifted, first)
+    # without the per-frame stream the field is ignored
+    assert np.array_equal(oracle.render_pt_sums(sd, m.make_params(w, h, 4, mode=m.MIRT_MODE_PT, frame_begin=9)),
+                          oracle.render_pt_sums(sd, m.make_params(w, h, 4, mode=m.MIRT_MODE_PT)))
+
+
 def test_frame_stream_frames_add_up_and_differ_from_per_sample_streams(oracle):
     w, h, n = 32, 20, 4
     sd = scene_data("three_spheres", w, h)

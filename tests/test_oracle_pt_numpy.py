@@ -42,12 +42,12 @@ def _np_scene(sd):
     return npt.Scene(cam, cr, mi, mats, sd.texels, sky)
 
 
-def _compare(oracle, sd, w, h, frames, n, bounces=8, flags=0, what="", px_ok=0.995, acc_ok=0.99):
+def _compare(oracle, sd, w, h, frames, n, bounces=8, flags=0, what="", px_ok=0.995, acc_ok=0.99, frames_before=0):
     spp = frames * n
-    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=flags, frame_spp=n)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=flags, frame_spp=n, frame_begin=frames_before)
     want = oracle.render(sd, p)
     sums = oracle.render_pt_sums(sd, p).astype(np.float64) / FIXED_ONE            # [h, w, 3] accumulated radiance
-    got, acc = npt.render_pt(_np_scene(sd), w, h, frames, n, bounces, flags & 7)
+    got, acc = npt.render_pt(_np_scene(sd), w, h, frames, n, bounces, flags & 7, frames_before=frames_before)
     assert got.shape == want.shape and (got[..., 3] == 255).all()
     d = np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max(axis=-1)
     close = np.isclose(acc.astype(np.float64), sums, rtol=1e-4, atol=1e-5)
@@ -117,3 +117,12 @@ def test_every_material_branch(oracle):
     cam = m.GpuCamera.new(fc.renderer_camera(), (w, h)).c
     sd = m.SceneData(cam, spheres, gm, texels)
     _compare(oracle, sd, w, h, 2, 2, what="every material", px_ok=0.99, acc_ok=0.98)
+
+
+def test_an_accumulation_that_starts_at_a_later_frame(oracle):
+    """MirtParams.frame_begin: the reference's frame_number survives render_progress.reset() (mod.rs:284, 350, 385), so the frames of
+    an accumulation that starts after k earlier render_frame calls are k + 1, k + 2, ...: the transcription run from frame 8 against the
+    C oracle with frame_begin = 7."""
+    w, h = 96, 54
+    sd = scene_data("three_spheres", w, h)
+    _compare(oracle, sd, w, h, 3, 2, what="frames 8..10", frames_before=7)

@@ -100,7 +100,7 @@ class MirtParams(C.Structure):
                 ("num_bounces", C.c_uint32), ("mode", C.c_uint32), ("flags", C.c_uint32),
                 ("seed", C.c_uint64), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("tile_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
-                ("sample_begin", C.c_uint32), ("frame_spp", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("sample_begin", C.c_uint32), ("frame_spp", C.c_uint32), ("frame_begin", C.c_uint32)]
 
 
 class MirtStats(C.Structure):

@@ -42,13 +42,14 @@ class SceneData:
 
 def make_params(width: int, height: int, spp: int, *, mode: int = _abi.MIRT_MODE_PARITY, num_bounces: int = 8,
                 flags: int = 0, seed: int = 0, row_begin: int = 0, row_end: int = 0, tile_rows: int = 0,
-                n_parts: int = 0, part: int = 0, sample_begin: int = 0, frame_spp: int = 0) -> _abi.MirtParams:
+                n_parts: int = 0, part: int = 0, sample_begin: int = 0, frame_spp: int = 0, frame_begin: int = 0) -> _abi.MirtParams:
     p = _abi.MirtParams()
     p.width, p.height, p.spp, p.num_bounces = width, height, spp, num_bounces
     p.mode, p.flags, p.seed = mode, flags, seed
     p.row_begin, p.row_end = row_begin, row_end
     p.tile_rows, p.n_parts, p.part, p.sample_begin = tile_rows, n_parts, part, sample_begin
     p.frame_spp = frame_spp
+    p.frame_begin = frame_begin
     return p
 
 

@@ -758,6 +758,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
     a.sample_begin = p->sample_begin;
     a.frame_spp = pt ? p->frame_spp : 0u;
+    a.frame_begin = pt ? p->frame_begin : 0u;
     a.row_begin = p->row_begin; a.tile_rows = p->tile_rows; a.n_parts = p->n_parts; a.part = p->part;
     a.out_rows = rows;
     for (int q = 0; q < 5; ++q) a.queue_routine[q] = c->queue_routine[q];

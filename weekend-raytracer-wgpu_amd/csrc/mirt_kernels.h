@@ -146,6 +146,7 @@ struct RenderArgs {
     uint64_t                n_texels;
     uint32_t n_spheres, n_mats;
     uint32_t width, height, spp, num_bounces, flags, seed_mix, sample_begin;
+    uint32_t frame_begin;                  // frames before this accumulation (MirtParams.frame_begin)
     uint32_t frame_spp;                    // > 0: the reference's per-frame RNG stream (MirtParams.frame_spp); lane-per-pixel schedule
     uint32_t row_begin, tile_rows, n_parts, part;
     uint32_t out_rows;                     // rows this launch writes

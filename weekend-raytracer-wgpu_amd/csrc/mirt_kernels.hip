@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
                         generate_primary(A, C, x, y, sample, rng, ro, rd);
                     } else {                     // the reference's stream: frame = sample / n + 1 seeds once, its n samples share it (g == 0)
                         if (sample % A.frame_spp == 0u)
-                            rng.state = jenkins_hash(((x + y * A.width) ^ jenkins_hash(sample / A.frame_spp + 1u)) ^ A.seed_mix);
+                            rng.state = jenkins_hash(((x + y * A.width) ^ jenkins_hash(A.frame_begin + sample / A.frame_spp + 1u)) ^ A.seed_mix);
                         generate_primary<false>(A, C, x, y, sample, rng, ro, rd);
                     }
                 }

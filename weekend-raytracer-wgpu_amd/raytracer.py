@@ -488,11 +488,10 @@ class Raytracer:
         105-122) for `num_samples_per_pixel` samples per frame (MirtParams.frame_spp).  The default keeps one stream
         per sample (frame_number = sample + 1), which does not depend on how samples are grouped into frames.
 
-        Scope of the match: frame f of an accumulation seeds with f = accumulated_samples / n + 1, i.e. every accumulation
-        starts at frame 1.  The reference's `frame_number` (mod.rs:284, 350) is NOT reset by `render_progress.reset()`
-        (mod.rs:385) and keeps counting on completed frames, so only the FIRST accumulation after construction draws the
-        reference's numbers; after `set_render_params` (a camera move) the streams differ by a frame offset -- equally
-        valid samples, but not the reference's: that case is parity-unpinned (nothing in the reference pins it either)."""
+        The reference's `frame_number` starts at 1 (mod.rs:284), advances with EVERY `render_frame` call -- frames that add nothing
+        because the accumulation is complete included (mod.rs:350) -- and is not reset by `render_progress.reset()` (mod.rs:385).
+        This class counts the same way (`frame_number`), and an accumulation that starts after k earlier frames seeds its j-th frame
+        with frame k + j + 1 (MirtParams.frame_begin = k), so a camera move mid-session continues the reference's streams."""
         render_params.validate()                                   # mod.rs:44-47
         self.reference_stream = reference_stream
         self.render_params = render_params
@@ -504,6 +503,8 @@ class Raytracer:
         self._ctx.set_scene(self.scene_data())
         self.last_stats: Optional[dict] = None
         self._accumulated = None        # RenderProgress (mod.rs:615-679): None = reset pending
+        self.frame_number = 1           # mod.rs:284; advanced by every render_frame call (mod.rs:350), never reset
+        self._frame_begin = 0           # frames rendered before the current accumulation started
 
     def scene_data(self) -> SceneData:
         return SceneData(self.camera.c, [s.to_c() for s in self.spheres], list(self.material_data),
@@ -515,7 +516,8 @@ class Raytracer:
             flags |= _abi.MIRT_FLAG_SKY_HOSEK
         return make_params(rp.viewport_size[0], rp.viewport_size[1], spp, mode=_abi.MIRT_MODE_PT,
                            num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed,
-                           frame_spp=rp.sampling.num_samples_per_pixel if self.reference_stream else 0)
+                           frame_spp=rp.sampling.num_samples_per_pixel if self.reference_stream else 0,
+                           frame_begin=self._frame_begin if self.reference_stream else 0)
 
     def render_frame(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
         """`Raytracer::render_frame` (mod.rs:303-351) without the wgpu draw: add
@@ -523,11 +525,13 @@ class Raytracer:
         (`RenderProgress::next_frame`, mod.rs:626-670), return the current estimate as RGBA8."""
         smp = self.render_params.sampling
         if self._accumulated is None:                          # first frame after a reset: clear
+            self._frame_begin = self.frame_number - 1          # this accumulation's frames are frame_number, frame_number + 1, ...
             self._ctx.accum_reset(self._params(smp.num_samples_per_pixel, seed, flags))
             self._accumulated = 0
         if self._accumulated + smp.num_samples_per_pixel <= smp.max_samples_per_pixel:
             self._ctx.accum_add(self._params(smp.num_samples_per_pixel, seed, flags))
             self._accumulated += smp.num_samples_per_pixel
+        self.frame_number += 1                                 # mod.rs:350: also when the accumulation was complete already
         return self._ctx.accum_resolve(self._params(smp.num_samples_per_pixel, seed, flags))
 
     def progress(self) -> float:                               # mod.rs:390-393
