@@ -622,8 +622,8 @@ def test_raytracer_render_frame_with_the_reference_stream(oracle):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MIRT_GRID_FUZZ_SEEDS", "10"))))      # deeper runs: MIRT_GRID_FUZZ_SEEDS=60
 def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
     """Random soups of 32-700 spheres (0-3 big ones besides the ground, random cell sizes through the radii, random
-    cameras with and without aperture, 2-8 bounces): the pool kernel's grid build -- all three pool geometries occur
-    (152 / 128 / 96 slots, whichever fits LDS beside the blob), walks in instalments, one scatter queue -- the strip
+    cameras with and without aperture, 2-8 bounces): the pool kernel's grid build -- several pool geometries occur
+    (160 / 152 / 128 / 96 slots, whichever fits LDS beside the blob), walks in instalments, candidate lists, one scatter queue -- the strip
     kernel's grid build and the default choice must all give the oracle's flat-scan image exactly."""
     rng = np.random.default_rng(7000 + seed)
     n = int(rng.integers(32, 700))
