@@ -831,9 +831,10 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // Path-traced lane-per-pixel units: 64 pixels x all samples -- or 32 / 16 pixels with the samples dealt to 2 / 4 groups of lanes:
         // smaller units are more units, and the last unit of a wave is then a smaller part of its life (config 2, 1080p x 100 spp, had 4
         // units per wave: 1.21 -> 0.98 ms with 32-pixel units).  Measured limits (tools/ab_libs.py, MIRT_PX_GROUPS): every group keeps
-        // >= 16 samples (1080p, three spheres: 32 spp -9 % with two groups, 16 spp +13 %), and the launch stays below ~65 000 units -- one
-        // dispenser atomic per unit serialises on its address (1080p x 100 spp with 16-pixel units, 129 600 of them: 1.49 ms; an
-        // 800x600 frame of the same scene, 30 000 units: 0.70 -> 0.39 ms).  Never with the reference's per-frame stream, whose samples
+        // >= 16 samples (1080p, three spheres: 32 spp -9 % with two groups, 16 spp +13 %), and the launch stays below ~65 000 units: beyond that the
+        // per-unit prologue and epilogue outweigh the finer tail (1080p x 100 spp with 16-pixel units, 129 600 of them: 1.49 ms; an
+        // 800x600 frame of the same scene, 30 000 units: 0.70 -> 0.39 ms).  It is not the dispenser's atomic: eight dispenser words instead
+        // of one were measured 1 ... 9 % slower.  Never with the reference's per-frame stream, whose samples
         // are sequentially dependent; the samples must divide evenly.
         if (pt && !frame_stream && tune.px_groups != 0) {
             const uint64_t max_units = 8ull * (uint64_t)c->cu_count * 32u;
