@@ -82,6 +82,8 @@ uint32_t jenkins_hash(uint32_t x)
 }
 
 constexpr int kEventPool = 64;
+constexpr int kDispenserStride = MIRT_DISPENSER_STRIDE;             // u32 words between the eight dispenser words of a launch (mirt_kernels.h)
+constexpr int kDispenserWords = 8 * kDispenserStride;
 
 constexpr float kRustPi = 3.14159265358979323846f;   // std::f32::consts::PI
 
@@ -205,6 +207,7 @@ struct Tuning {
     double   grid_cell = 0.0;         // MIRT_GRID_CELL: cell size of the uniform grid in median radii
     double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
     int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
+    int      spread_units = -1;       // MIRT_SPREAD_UNITS=0: strip-type launches use one dispenser word (A/B runs)
     int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed / dealt round-robin (A/B runs)
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
@@ -222,6 +225,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_POOL_BLOCKS_PER_CU")) { const uint32_t v = (uint32_t)std::atoi(e); if (v >= 1) t.pool_blocks_per_cu = v; }
     if (const char* e = std::getenv("MIRT_GRID_CELL")) { const double v = std::atof(e); if (v >= 1.0 && v <= 64.0) t.grid_cell = v; }
     if (const char* e = std::getenv("MIRT_PINHOLE")) t.pinhole = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_SPREAD_UNITS")) t.spread_units = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_STATIC_UNITS")) t.static_units = (e[0] == '1') ? 1 : 0;
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
@@ -303,7 +307,7 @@ struct MirtContext {
     // per-launch state: every launch owns the dispenser word and the counter block of its event slot, so
     // launches of one context that overlap on different streams cannot disturb each other
     unsigned long long* d_counters = nullptr;      // [kEventPool][kNumCounters]
-    uint32_t*           d_work_counter = nullptr;  // [kEventPool]
+    uint32_t*           d_work_counter = nullptr;  // [kEventPool][kDispenserWords]: word 0 = the launch's dispenser; words kDispenserStride k = the 8 dispensers of a lane-per-pixel launch
     size_t              last_slot = 0;             // event slot of the last launch (its counters feed MirtStats)
     hipEvent_t          ev_accum = nullptr;        // end of the last launch that adds into d_accum
     bool                accum_pending = false;
@@ -458,7 +462,7 @@ int mirt_ctx_create(int device, MirtContext** out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters * kEventPool);
-    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool);
+    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool * kDispenserWords);
     if (e != hipSuccess) {
         const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         mirt_ctx_destroy(c);
@@ -711,8 +715,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
     // pools still leave >= 16 waves per CU resident beside the scene tables; the sample counts from which it does are
-    // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 40 for scenes
-    // with several shading routines, 304 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
+    // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 48 for scenes
+    // with several shading routines, 600 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
     // beat: single metal sphere, 1080p x 100 spp, 1.38 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
     // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
@@ -752,7 +756,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // THIS launch's by-value copy of the camera; the caller's struct is never touched
     { const uint32_t flag = (pt && tune.pinhole != 0 && camera_is_pinhole(c->cam)) ? 1u : 0u; std::memcpy(&a.cam._padding5, &flag, 4); }
     a.spheres = c->d_spheres; a.mats = c->d_mats; a.pmats = c->d_pmats; a.texels = c->d_texels; a.sky = c->d_sky;
-    a.out = d_out; a.counters = c->d_counters + ev * mirt::kNumCounters; a.work_counter = c->d_work_counter + ev; a.accum = d_accum;
+    a.out = d_out; a.counters = c->d_counters + ev * mirt::kNumCounters; a.work_counter = c->d_work_counter + ev * kDispenserWords; a.accum = d_accum;
     a.n_texels = c->n_texels; a.n_spheres = c->n_spheres; a.n_mats = c->n_mats;
     a.width = p->width; a.height = p->height; a.spp = p->spp; a.num_bounces = p->num_bounces; a.flags = p->flags;
     a.seed_mix = jenkins_hash((uint32_t)p->seed ^ jenkins_hash((uint32_t)(p->seed >> 32)));
@@ -830,24 +834,22 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (by_pixel) {
         // Path-traced lane-per-pixel units: 64 pixels x all samples -- or 32 / 16 pixels with the samples dealt to 2 / 4 groups of lanes:
         // smaller units are more units, and the last unit of a wave is then a smaller part of its life (config 2, 1080p x 100 spp, had 4
-        // units per wave: 1.21 -> 0.98 ms with 32-pixel units).  Measured limits (tools/ab_libs.py, MIRT_PX_GROUPS): every group keeps
-        // >= 16 samples (1080p, three spheres: 32 spp -9 % with two groups, 16 spp +13 %), and the launch stays below ~65 000 units: beyond that the
-        // per-unit prologue and epilogue outweigh the finer tail (1080p x 100 spp with 16-pixel units, 129 600 of them: 1.49 ms; an
-        // 800x600 frame of the same scene, 30 000 units: 0.70 -> 0.39 ms).  It is not the dispenser's atomic: eight dispenser words instead
-        // of one were measured 1 ... 9 % slower.  Never with the reference's per-frame stream, whose samples
-        // are sequentially dependent; the samples must divide evenly.
+        // units per wave: 1.21 ms; 16-pixel units, with the eight-word dispenser they need: 0.86).  Measured (tools/ab_libs.py with
+        // MIRT_PX_GROUPS, profiles/r03_flat_ab.txt block 9; 1080p unless stated): as many groups as leave each >= 8 samples -- three spheres
+        // at 32 / 16 / 8 spp: 1 / 2 / 4 groups 1.33 / 1.20 / 1.16, 0.68 / 0.63 / 0.66, 0.36 / 0.37 / 0.43 ms; config 2 1.17 / 0.93 / 0.86;
+        // the same at 3840x2160 3.20 / 2.96 / 2.89, at 800x600 0.71 / 0.41 / 0.33 -- and one more for many-sphere scenes (RTIOW 8 spp:
+        // 1.54 / 1.40).  The samples must divide evenly; never with the reference's per-frame stream (sequentially dependent samples).
         if (pt && !frame_stream && tune.px_groups != 0) {
-            const uint64_t max_units = 8ull * (uint64_t)c->cu_count * 32u;
-            while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= 16u &&
-                   ((npix << (a.px_groups_log2 + 1u)) + 63u) / 64u <= max_units)
+            const uint32_t min_share = use_grid ? 4u : 8u;
+            while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= min_share)
                 a.px_groups_log2 += 1u;
             if (tune.px_groups > 0 && p->spp % (1u << (tune.px_groups - 1)) == 0u) a.px_groups_log2 = (uint32_t)tune.px_groups - 1u;
         }
         a.n_units = (uint32_t)((npix + (64u >> a.px_groups_log2) - 1u) / (64u >> a.px_groups_log2));
-        // units dealt round-robin instead of dispensed: path-traced mode below 8 spp (measured crossover, tools/low_spp.py); parity mode
+        // units dealt round-robin instead of dispensed: path-traced mode below 4 spp (measured crossover; 8 before the eight-word dispenser); parity mode
         // always -- its lane = pixel units are a few dozen sphere tests each, and one dispenser atomic per unit (14 ns, serialised on
         // its address) was the whole kernel time: 7 500 units of an 800x600 frame at 2 spp 94 us whatever the work
-        a.static_units = (!pt || p->spp < 8u) ? 1u : 0u;
+        a.static_units = (!pt || p->spp < 4u) ? 1u : 0u;  // (three spheres 1080p: 2 spp 0.132 ms dealt / 0.169 dispensed, 4 spp 0.244 / 0.234)
         if (tune.static_units >= 0) a.static_units = (uint32_t)tune.static_units;
     }
 
@@ -879,7 +881,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
     const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
-    if (!(by_pixel && a.static_units))           // units dealt round-robin never touch the dispenser: one memset node less per interactive frame
+    // strip-type kernels (path-traced strip kernel, both schedules; parity kernel) with dispensed units: eight dispenser words
+    // (mirt_kernels.hip: next_unit_any).  The pooled kernel's strips are long (a few thousand per millisecond): one word.
+    a.spread_units = (!pool && a.static_units == 0u && tune.spread_units != 0) ? 1u : 0u;
+    if (a.spread_units) {
+        for (uint32_t x = 0; x < 8u; ++x)
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(a.work_counter + (size_t)kDispenserStride * x), (int)(launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u), 1, stream));
+    } else if (!(by_pixel && a.static_units))    // units dealt round-robin never touch the dispenser: one memset node less per interactive frame
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));

@@ -74,6 +74,9 @@ struct GridHeader {
     uint32_t off_recs;      // ... and every sphere's, by id
 };
 static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte copies");
+#ifndef MIRT_DISPENSER_STRIDE
+#define MIRT_DISPENSER_STRIDE 1024           // u32 words between a launch's eight dispenser words: 4 KB, so that they sit in different memory channels
+#endif
 constexpr uint32_t kGridMinSpheres = 32;
 constexpr uint32_t kGridMaxCells   = 8192;
 
@@ -105,13 +108,14 @@ constexpr uint32_t kGridPoolSlotChoices[4] = { 160, 152, 128, 96 };   // the lar
 // Samples per pixel from which the pooled kernel is the default (below: the strip kernel, lane = pixel).  A 16-pixel strip
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
-//   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40
-//   (round 3, two sample groups from 32 spp on: strip 1.37 / 1.65 / 1.96 ms at 32 / 40 / 48 spp, pool 1.55 / 1.65 / 1.76: still 40)
-//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose; round 3, 32-pixel units with two sample groups): strip
-//   1.06 / 2.05 / 4.05 / 9.59 ms at 100 / 200 / 400 / 1000 spp, pool 1.81 / 2.39 / 3.77 / 7.98                      -> 304
-//   many-sphere scenes (grid build, RTIOW): strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66   -> 16
-constexpr uint32_t kPoolMinSpp           = 40;
-constexpr uint32_t kPoolMinSppOneRoutine = 304;
+//   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40 (round 2)
+//     round 3 (sample groups + eight-word dispenser): strip 1.25 / 1.55 / 1.84 / 2.12 ms at 32 / 40 / 48 / 56 spp, pool 1.56 / 1.67 / 1.79 / 1.96   -> 48
+//   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): round 2 184; round 3: strip 0.93 / 1.78 / 3.55 / 5.21 / 6.98 /
+//     8.48 ms at 100 / 200 / 400 / 600 / 800 / 1000 spp, pool 1.81 / 2.42 / 3.85 / 5.17 / 6.52 / 7.96                                           -> 600
+//   many-sphere scenes (grid build, RTIOW): round 2: strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66 -> 16;
+//     round 3: strip 1.52 / 2.26 / 2.83 / 4.05 ms at 8 / 12 / 16 / 24 spp, pool 2.20 / 2.53 / 2.87 / 3.40                                      -> 16
+constexpr uint32_t kPoolMinSpp           = 48;
+constexpr uint32_t kPoolMinSppOneRoutine = 600;
 constexpr uint32_t kPoolMinSppGrid       = 16;
 
 enum CounterSlot : uint32_t {
@@ -152,6 +156,7 @@ struct RenderArgs {
     uint32_t out_rows;                     // rows this launch writes
     uint32_t n_units;                      // work units (strips) the dispenser hands out
     uint32_t static_units;                 // lane-per-pixel strip kernel: units dealt round-robin instead of dispensed
+    uint32_t spread_units;                 // strip-type kernels: units from eight dispenser words (unit u <-> word u mod 8; next_unit_any)
     uint32_t px_groups_log2;               // lane-per-pixel strip kernel: a unit is 64 >> g pixels, their samples dealt to 1 << g groups of lanes
     // pool kernel, guided self-scheduling: level l = strips of (kStripPixels >> l) pixels; it starts at unit
     // lvl_unit[l] / pixel lvl_pix[l] (entry kStripLevels = end).  Strips shrink 16 -> 1 pixels towards the end of

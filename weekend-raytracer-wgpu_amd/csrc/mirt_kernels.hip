@@ -11,7 +11,7 @@
 //   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
 //                          paths in LDS, queued by the shading routine they wait for, and always
 //                          runs ONE routine on up to 64 of them — the material switch no longer
-//                          serialises inside a wave (default from 40 / 304 / 16 samples per pixel on for scenes
+//                          serialises inside a wave (default from 48 / 600 / 16 samples per pixel on for scenes
 //                          with several / one shading routine / many spheres: mirt_kernels.h, kPoolMinSpp*).
 //
 // Every pixel's radiance is summed in 64-bit fixed point (exact, order-independent), so the three
@@ -117,6 +117,29 @@ MIRT_DEV uint32_t next_unit(const RenderArgs& A, uint32_t lane)
     uint32_t s = 0;
     if (lane == 0) s = atomicAdd(A.work_counter, 1u);
     return __builtin_amdgcn_readfirstlane(s);
+}
+
+// The strip kernels' launches of many small units -- 64 800 units of 32 pixels in a 1 ms launch (config 2) -- run into the rate of ONE
+// dispenser word: a returning device-scope atomic on one address saturates at ~88 per microsecond (MI355X_MICROARCH.md, "dequeue").  Such
+// launches (A.spread_units) use EIGHT words, 4 KB apart so that they sit in different memory channels (64 bytes apart they gained nothing);
+// word x hands out the units u = 8 k + x.  A wave asks the word of its block's XCD first (blockIdx mod 8: workgroups are dealt to the XCDs
+// round-robin, so the eight words see equal traffic; nothing depends on that for correctness) and the others in turn once it has run
+// dry: every unit is taken exactly once, and a wave gets "no unit" (>= n_units) only after all eight words have run dry -- the loop that
+// calls this ends for every wave.
+MIRT_DEV uint32_t next_unit_any(const RenderArgs& A, uint32_t lane)
+{
+    if (A.spread_units == 0u) return next_unit(A, lane);
+    const uint32_t home = blockIdx.x & 7u;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 8u; ++j) {                    // wave-uniform; kept a loop (unrolled it costs the strip kernels ~45 scalar registers)
+        const uint32_t x = (home + j) & 7u;
+        const uint32_t share = A.n_units > x ? (A.n_units - x + 7u) >> 3 : 0u;      // units of word x: u = 8 k + x < n_units
+        uint32_t k = 0xffffffffu;
+        if (lane == 0) k = atomicAdd(A.work_counter + (size_t)MIRT_DISPENSER_STRIDE * x, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k < share) return 8u * k + x;
+    }
+    return 0xffffffffu;
 }
 
 MIRT_DEV uint32_t sat_u32(float f)   // Rust `as u32` / WGSL u32(): truncate, saturate, NaN -> 0
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_parity_kernel(RenderArgs
     work.clear();
 
     const uint32_t grid_waves = gridDim.x * (kBlockThreads / 64u);
-    for (uint32_t strip = first_unit(); strip < A.n_units; strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit(A, lane)) {
+    for (uint32_t strip = first_unit(); strip < A.n_units; strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit_any(A, lane)) {
         if constexpr (BY_PIXEL) {
             const uint32_t pi = strip * 64u + lane;
             const bool inside = pi < npix;
@@ -1377,7 +1400,7 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
     // (Dispensing these units in batches -- a static first batch per wave, then guided batches of (units left) / (waves) per atomic -- was
     //  measured: 16 ... 110 % SLOWER than one unit per atomic at every unit size; eight dispenser words instead of one: 1 ... 9 % slower.)
     for (uint32_t strip = first_unit(); strip < A.n_units;
-         strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit(A, lane)) {
+         strip = (BY_PIXEL && A.static_units) ? strip + grid_waves : next_unit_any(A, lane)) {
         if constexpr (BY_PIXEL) {
             // arguments needed once per unit are read from the kernarg segment here and now (per_strip_args) instead of
             // living in SGPRs across the sample loop, which the 8-waves-per-SIMD build has too few of
