@@ -136,7 +136,7 @@ enum {
     MIRT_FLAG_NO_SRGB        = 1u << 2, /* skip the sRGB OETF the Bgra8UnormSrgb surface applies (main.rs:465) */
     MIRT_FLAG_COUNT_WORK     = 1u << 3, /* run the counting build of the kernel: fills MirtStats work counters */
     /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the pooled kernel
-     * (paths queued by shading routine in LDS) from a measured number of samples per pixel on -- 48 for scenes with
+     * (paths queued by shading routine in LDS) from a measured number of samples per pixel on -- 28 for scenes with
      * several shading routines, 600 for scenes with one, 16 for many-sphere scenes (csrc/mirt_kernels.h, kPoolMinSpp*)
      * -- and the strip kernel below (lane = pixel under 64 samples per pixel, else lane = sample).
      * In parity mode MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule (default below 64 samples per pixel:

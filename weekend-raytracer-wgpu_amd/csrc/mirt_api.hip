@@ -715,7 +715,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const mirt::PoolConfig pc = kx::pool_config(pool_cfg, pool_nq);
     // Default schedule: the pooled kernel pays off when a strip holds enough samples to keep the pool full and the
     // pools still leave >= 16 waves per CU resident beside the scene tables; the sample counts from which it does are
-    // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 48 for scenes
+    // measured crossovers against the strip kernel's lane-per-pixel schedule (mirt_kernels.h: kPoolMinSpp*): 28 for scenes
     // with several shading routines, 600 for single-routine scenes (nothing diverges there, so lane = pixel is hard to
     // beat: single metal sphere, 1080p x 100 spp, 1.38 ms against the pool's 1.82 and the lane-per-sample schedule's 2.27),
     // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
@@ -881,9 +881,11 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
     const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
-    // strip-type kernels (path-traced strip kernel, both schedules; parity kernel) with dispensed units: eight dispenser words
-    // (mirt_kernels.hip: next_unit_any).  The pooled kernel's strips are long (a few thousand per millisecond): one word.
-    a.spread_units = (!pool && a.static_units == 0u && tune.spread_units != 0) ? 1u : 0u;
+    // kernels with dispensed units take them from eight dispenser words (mirt_kernels.hip: next_unit_any): the strip-type kernels
+    // (path-traced strip kernel, both schedules; parity kernel) always.
+    // The pooled kernel's strips last long at high sample counts (config 3: 9 atomics per microsecond); below 128 spp they do not
+    // (three spheres, 1080p, pool forced: 48 / 64 / 100 / 200 spp -13.5 / -8.5 / -2 / +1 % with eight words; RTIOW 16 spp -4.5 %).
+    a.spread_units = (a.static_units == 0u && tune.spread_units != 0 && (!pool || p->spp < 128u)) ? 1u : 0u;
     if (a.spread_units) {
         for (uint32_t x = 0; x < 8u; ++x)
             HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(a.work_counter + (size_t)kDispenserStride * x), (int)(launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u), 1, stream));

@@ -109,12 +109,13 @@ constexpr uint32_t kGridPoolSlotChoices[4] = { 160, 152, 128, 96 };   // the lar
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):
 //   several shading routines (config 3): strip 1.58 / 1.73 / 1.94 ms at 36 / 40 / 44 spp, pool 1.61 / 1.67 / 1.74   -> 40 (round 2)
-//     round 3 (sample groups + eight-word dispenser): strip 1.25 / 1.55 / 1.84 / 2.12 ms at 32 / 40 / 48 / 56 spp, pool 1.56 / 1.67 / 1.79 / 1.96   -> 48
+//     round 3 (sample groups; eight-word dispenser in both kernels): strip 0.98 / 1.13 / 1.24 / 1.37 / 1.54 ms at 24 / 28 / 32 / 36 / 40 spp, pool
+//     1.00 / 1.11 / 1.21 / 1.30 / 1.41 (main.rs 5-sphere scene: 1.32 / 1.65 against 1.33 / 1.55 at 24 / 32 spp)                                   -> 28
 //   ONE routine (config 2, no divergence for the lane-per-pixel kernel to lose): round 2 184; round 3: strip 0.93 / 1.78 / 3.55 / 5.21 / 6.98 /
 //     8.48 ms at 100 / 200 / 400 / 600 / 800 / 1000 spp, pool 1.81 / 2.42 / 3.85 / 5.17 / 6.52 / 7.96                                           -> 600
 //   many-sphere scenes (grid build, RTIOW): round 2: strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66 -> 16;
-//     round 3: strip 1.52 / 2.26 / 2.83 / 4.05 ms at 8 / 12 / 16 / 24 spp, pool 2.20 / 2.53 / 2.87 / 3.40                                      -> 16
-constexpr uint32_t kPoolMinSpp           = 48;
+//     round 3: strip 1.54 / 2.19 / 2.70 ms at 8 / 12 / 16 spp, pool 1.99 / 2.28 / 2.61                                                          -> 16
+constexpr uint32_t kPoolMinSpp           = 28;
 constexpr uint32_t kPoolMinSppOneRoutine = 600;
 constexpr uint32_t kPoolMinSppGrid       = 16;
 

@@ -11,7 +11,7 @@
 //   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
 //                          paths in LDS, queued by the shading routine they wait for, and always
 //                          runs ONE routine on up to 64 of them — the material switch no longer
-//                          serialises inside a wave (default from 48 / 600 / 16 samples per pixel on for scenes
+//                          serialises inside a wave (default from 28 / 600 / 16 samples per pixel on for scenes
 //                          with several / one shading routine / many spheres: mirt_kernels.h, kPoolMinSpp*).
 //
 // Every pixel's radiance is summed in 64-bit fixed point (exact, order-independent), so the three
@@ -126,8 +126,10 @@ MIRT_DEV uint32_t next_unit(const RenderArgs& A, uint32_t lane)
 // round-robin, so the eight words see equal traffic; nothing depends on that for correctness) and the others in turn once it has run
 // dry: every unit is taken exactly once, and a wave gets "no unit" (>= n_units) only after all eight words have run dry -- the loop that
 // calls this ends for every wave.
-MIRT_DEV uint32_t next_unit_any(const RenderArgs& A, uint32_t lane)
+MIRT_DEV uint32_t next_unit_any(const RenderArgs& A_unused, uint32_t lane)
 {
+    (void)A_unused;
+    const RenderArgs& A = per_strip_args();        // once per unit: read from the kernarg segment here, not held in scalar registers across the hot loop
     if (A.spread_units == 0u) return next_unit(A, lane);
     const uint32_t home = blockIdx.x & 7u;
 #pragma unroll 1
