@@ -129,6 +129,10 @@ enum {
     MIRT_MODE_PT = 1
 };
 
+/* Most samples per pixel ONE render / accum_add call takes (MIRT_ERR_SPP_RANGE above): the kernels count the work items of a unit --
+ * up to 64 pixels x spp -- in 32 bits.  The reference's UI offers 1..=64 per frame and accumulates to max_samples_per_pixel (mod.rs:599-613). */
+#define MIRT_MAX_SPP_PER_CALL (1u << 24)
+
 /* Flags (MIRT_MODE_PT only, except MIRT_FLAG_COUNT_WORK which both modes honour). */
 enum {
     MIRT_FLAG_SKY_HOSEK      = 1u << 0, /* sky = Hosek-Wilkie blob (wgsl:154-166,316-343); default: RTIOW gradient */
@@ -171,7 +175,7 @@ enum {
 typedef struct MirtParams {
     uint32_t width;        /* `vp_size[0] as u32` layer.rs:270-275 */
     uint32_t height;
-    uint32_t spp;          /* `sampling.num_samples_per_pixel` layer.rs:316 */
+    uint32_t spp;          /* `sampling.num_samples_per_pixel` layer.rs:316; 1 .. MIRT_MAX_SPP_PER_CALL (progressive accumulation adds calls up) */
     uint32_t num_bounces;  /* PT mode; SamplingParams.num_bounces mod.rs:602 */
     uint32_t mode;         /* MIRT_MODE_* */
     uint32_t flags;        /* MIRT_FLAG_* */
@@ -255,6 +259,7 @@ typedef enum MirtStatus {
     MIRT_ERR_NO_DEVICE            = -20,
     MIRT_ERR_HIP                  = -21,
     MIRT_ERR_ALLOC                = -22,
+    MIRT_ERR_SPP_RANGE            = -24, /* spp > MIRT_MAX_SPP_PER_CALL, or sample_begin (the samples accumulated so far) + spp reaches 2^32 */
     MIRT_ERR_IMAGE_DECODE         = -23  /* mirt_jpeg_*: not a JPEG this decoder handles (TextureError::ImageLoadError, texture.rs:193-199) */
 } MirtStatus;
 

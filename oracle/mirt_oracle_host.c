@@ -71,6 +71,7 @@ int mirt_oracle_check(const MirtScene* scene, const MirtParams* params)
     if (scene->n_texels && !scene->texels) return MIRT_ERR_NULL_POINTER;
     if (params->width == 0 || params->height == 0) return MIRT_ERR_VIEWPORT_SIZE;
     if (params->spp == 0) return MIRT_ERR_SPP_ZERO;
+    if (params->spp > MIRT_MAX_SPP_PER_CALL || (uint64_t)params->sample_begin + params->spp > 0xffffffffull) return MIRT_ERR_SPP_RANGE;
     if (params->mode != MIRT_MODE_PARITY && params->mode != MIRT_MODE_PT) return MIRT_ERR_BAD_MODE;
     uint32_t rb, re;
     if (!rows_valid(params, &rb, &re)) return MIRT_ERR_BAD_ROWS;

@@ -94,6 +94,7 @@ pub struct MirtScene {
 
 pub const MIRT_MODE_PARITY: u32 = 0;
 pub const MIRT_MODE_PT: u32 = 1;
+pub const MIRT_MAX_SPP_PER_CALL: u32 = 1 << 24;
 pub const MIRT_FLAG_SKY_HOSEK: u32 = 1 << 0;
 pub const MIRT_FLAG_NO_TONEMAP: u32 = 1 << 1;
 pub const MIRT_FLAG_NO_SRGB: u32 = 1 << 2;
@@ -127,6 +128,7 @@ pub const MIRT_ERR_NO_DEVICE: c_int = -20;
 pub const MIRT_ERR_HIP: c_int = -21;
 pub const MIRT_ERR_ALLOC: c_int = -22;
 pub const MIRT_ERR_IMAGE_DECODE: c_int = -23;
+pub const MIRT_ERR_SPP_RANGE: c_int = -24;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

@@ -29,6 +29,7 @@ def test_render_before_set_scene():
 @pytest.mark.parametrize("kw,status", [
     (dict(width=0), "MIRT_ERR_VIEWPORT_SIZE"), (dict(height=0), "MIRT_ERR_VIEWPORT_SIZE"),
     (dict(spp=0), "MIRT_ERR_SPP_ZERO"), (dict(mode=7), "MIRT_ERR_BAD_MODE"),
+    (dict(spp=(1 << 24) + 1), "MIRT_ERR_SPP_RANGE"), (dict(spp=2, sample_begin=0xffffffff), "MIRT_ERR_SPP_RANGE"),
     (dict(row_begin=10, row_end=5), "MIRT_ERR_BAD_ROWS"), (dict(row_end=99), "MIRT_ERR_BAD_ROWS"),
     (dict(tile_rows=4, n_parts=2, part=2), "MIRT_ERR_BAD_ROWS"),
 ])

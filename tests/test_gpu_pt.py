@@ -578,6 +578,20 @@ def test_frame_stream_param_errors(gpu_ctx, oracle):
         assert oracle.render_status(sd.as_c(), p) == m._abi.MIRT_ERR_FRAME_SPP
 
 
+@pytest.mark.parametrize("flags", [0, m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL])
+def test_the_top_of_the_sample_range(gpu_ctx, oracle, flags):
+    """Sample indices run to 2^32 - 1 (MIRT_ERR_SPP_RANGE beyond): the last ones render like any others, in every kernel."""
+    w, h = 40, 12
+    sd = scene_data("three_spheres", w, h)
+    gpu_ctx.set_scene(sd)
+    for spp in (2, 70):
+        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, sample_begin=0xffffffff - spp, flags=flags)
+        assert np.array_equal(gpu_ctx.render(p), oracle.render(sd, p))
+    with pytest.raises(m.MirtError) as e:
+        gpu_ctx.render(m.make_params(w, h, 70, mode=m.MIRT_MODE_PT, sample_begin=0xffffffff - 69, flags=flags))
+    assert e.value.status_name == "MIRT_ERR_SPP_RANGE"
+
+
 def test_accumulation_refuses_a_frame_stream_that_would_start_mid_frame(gpu_ctx):
     """mirt_ctx_accum_add continues at the samples accumulated so far, whatever sample_begin the caller passes: that count must be
     a multiple of frame_spp, or the lane-per-pixel kernel would draw from an unseeded stream until the next frame boundary."""

@@ -177,6 +177,18 @@ def test_frame_stream_frames_add_up_and_differ_from_per_sample_streams(oracle):
     assert oracle.render_status(sd.as_c(), m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, frame_spp=4, sample_begin=2)) == m._abi.MIRT_ERR_FRAME_SPP
 
 
+def test_sample_range_limits(oracle):
+    """include/mirt.h MIRT_MAX_SPP_PER_CALL / MIRT_ERR_SPP_RANGE: at most 2^24 samples per pixel in one call, sample indices below 2^32."""
+    w, h = 8, 4
+    sd = scene_data("three_spheres", w, h)
+    for mode in (m.MIRT_MODE_PT, m.MIRT_MODE_PARITY):
+        assert oracle.render_status(sd.as_c(), m.make_params(w, h, (1 << 24) + 1, mode=mode)) == m._abi.MIRT_ERR_SPP_RANGE
+        assert oracle.render_status(sd.as_c(), m.make_params(w, h, 2, mode=mode, sample_begin=0xffffffff)) == m._abi.MIRT_ERR_SPP_RANGE
+    # the last samples of the range render (and differ from the first ones)
+    top = oracle.render_pt_sums(sd, m.make_params(w, h, 2, mode=m.MIRT_MODE_PT, sample_begin=0xfffffffd))
+    assert top.any() and not np.array_equal(top, oracle.render_pt_sums(sd, m.make_params(w, h, 2, mode=m.MIRT_MODE_PT)))
+
+
 def test_frame_stream_second_sample_continues_the_first_samples_stream(oracle):
     """Empty world: a sample consumes exactly 4 variates (pixel jitter x, y, lens r, lens angle; wgsl:114-117, 456-478) and
     the sky is hit at once.  With frame_spp = 2 the second sample's jitter must therefore be variates 4 and 5 of the

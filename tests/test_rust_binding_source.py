@@ -48,12 +48,18 @@ def test_every_mode_and_flag_constant_matches_the_header():
 
 def test_every_status_code_matches_the_header():
     codes = {**_header_enum_constants("MIRT_OK"), **_header_enum_constants("MIRT_ERR_")}
-    assert codes["MIRT_OK"] == 0 and len(codes) == 21 and all(v < 0 for k, v in codes.items() if k != "MIRT_OK")
+    assert codes["MIRT_OK"] == 0 and len(codes) == 22 and all(v < 0 for k, v in codes.items() if k != "MIRT_OK")
     in_rust = dict((n, int(v)) for n, v in re.findall(r"pub const (MIRT_(?:OK|ERR_[A-Z_]+)): c_int = (-?\d+);", RS))
     assert in_rust == codes, set(in_rust.items()) ^ set(codes.items())
     for name, value in codes.items():
         if name != "MIRT_OK":
             assert _abi.STATUS[value] == name and getattr(_abi, name) == value
+
+
+def test_the_per_call_sample_limit_matches_the_header():
+    value = eval(re.search(r"#define MIRT_MAX_SPP_PER_CALL \(([^)]+)\)", HEADER).group(1).replace("u", ""))
+    assert value == 1 << 24 == _abi.MIRT_MAX_SPP_PER_CALL
+    assert eval(re.search(r"pub const MIRT_MAX_SPP_PER_CALL: u32 = ([^;]+);", RS).group(1)) == value
 
 
 def _rust_type_of(ctype):

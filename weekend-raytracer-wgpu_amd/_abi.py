@@ -9,6 +9,7 @@ import ctypes as C
 
 MIRT_MODE_PARITY = 0
 MIRT_MODE_PT = 1
+MIRT_MAX_SPP_PER_CALL = 1 << 24
 
 MIRT_FLAG_SKY_HOSEK = 1 << 0
 MIRT_FLAG_NO_TONEMAP = 1 << 1
@@ -44,6 +45,7 @@ STATUS = {
     -21: "MIRT_ERR_HIP",
     -22: "MIRT_ERR_ALLOC",
     -23: "MIRT_ERR_IMAGE_DECODE",
+    -24: "MIRT_ERR_SPP_RANGE",
 }
 for _code, _name in STATUS.items():
     globals()[_name] = _code

@@ -354,6 +354,7 @@ const char* mirt_status_string(int status)
     case MIRT_ERR_HIP: return "MIRT_ERR_HIP";
     case MIRT_ERR_ALLOC: return "MIRT_ERR_ALLOC";
     case MIRT_ERR_IMAGE_DECODE: return "MIRT_ERR_IMAGE_DECODE";
+    case MIRT_ERR_SPP_RANGE: return "MIRT_ERR_SPP_RANGE";
     default: return "MIRT_ERR_UNKNOWN";
     }
 }
@@ -659,6 +660,10 @@ static int check_params(const MirtContext* c, const MirtParams* p)
     if (p->width == 0 || p->height == 0)
         return fail(MIRT_ERR_VIEWPORT_SIZE, "viewport_size elements cannot be zero: (%u, %u)", p->width, p->height);
     if (p->spp == 0) return fail(MIRT_ERR_SPP_ZERO, "spp is zero");
+    // the kernels count a unit's work items (up to 64 pixels x spp) and the samples of a pixel in 32 bits
+    if (p->spp > MIRT_MAX_SPP_PER_CALL || (uint64_t)p->sample_begin + p->spp > 0xffffffffull)
+        return fail(MIRT_ERR_SPP_RANGE, "spp %u (from sample %u) is out of range: at most %u samples per pixel in one call, sample indices below 2^32",
+                    p->spp, p->sample_begin, (unsigned)MIRT_MAX_SPP_PER_CALL);
     if (p->mode != MIRT_MODE_PARITY && p->mode != MIRT_MODE_PT) return fail(MIRT_ERR_BAD_MODE, "unknown mode %u", p->mode);
     uint32_t rb, re;
     if (!rows_valid(p, &rb, &re)) return fail(MIRT_ERR_BAD_ROWS, "invalid row selection [%u,%u) of %u, part %u/%u", p->row_begin, p->row_end, p->height, p->part, p->n_parts);
@@ -1047,6 +1052,8 @@ int mirt_ctx_accum_add(MirtContext* c, const MirtParams* p, void* hip_stream)
     q.sample_begin = c->accum_samples;                  // continue the RNG stream where the last frame stopped
     // check_params saw the CALLER's sample_begin; the one that counts is this one.  A caller that changes frame_spp between adds
     // without a reset would start mid-frame: the lane-per-pixel kernel seeds only at frame boundaries, so the sums would be wrong silently.
+    if ((uint64_t)q.sample_begin + q.spp > 0xffffffffull)
+        return fail(MIRT_ERR_SPP_RANGE, "%u samples accumulated so far + %u would pass 2^32: reset first", q.sample_begin, q.spp);
     if (q.frame_spp != 0 && q.sample_begin % q.frame_spp != 0)
         return fail(MIRT_ERR_FRAME_SPP, "frame_spp %u does not divide the %u samples accumulated so far: reset first", q.frame_spp, q.sample_begin);
     rc = launch_render(c, &q, nullptr, hip_stream ? (hipStream_t)hip_stream : c->stream, c->d_accum);
