@@ -17,7 +17,10 @@ BENCH="python3 $PWD/bench.py --config $CONFIG --steps $STEPS --warmup 1 --no-cpu
 # pass 0 is the FULL line -- cpu_baseline and verified_rows included, 10 timed steps: the one profiles/<tag>_bench.json keeps; the
 # rocprofv3 passes below run the same workload without the CPU legs (they would only be profiled host time)
 python3 $PWD/bench.py --config $CONFIG --steps ${FULL_STEPS:-10} --warmup 2 ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { tail -20 "$OUT/trace.log"; exit 1; }
+# the trace pass runs the driver's default step counts (20 timed + 3 warm-up): its per-kernel AVERAGE is then the steady state the HIP events of
+# pass 0 see, not a mean over three launches and a cold first one
+BENCH_TRACE="python3 $PWD/bench.py --config $CONFIG --steps ${TRACE_STEPS:-20} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-}"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH_TRACE > "$OUT/trace.log" 2>&1 || { tail -20 "$OUT/trace.log"; exit 1; }
 i=0
 GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
          "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE GRBM_COUNT")
