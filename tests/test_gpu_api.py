@@ -337,6 +337,31 @@ def _soup(n_small, n_large, spread):
     return sph
 
 
+def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
+    """A launch takes its work units from dispenser words that belong to its event slot and start at zero (no memset node in
+    front of the kernel); the slots are re-zeroed when the pool of 64 is folded.  150 dispensed launches in a row -- the fold
+    happens inside mirt_ctx_render_device, twice -- must all produce the oracle's frame, in the strip and in the pooled kernel."""
+    import torch
+    w, h = 800, 400                  # 20 000 units of 16 pixels: more than the waves of a launch, so most units come from the dispenser
+    sd = scene_data("three_spheres", w, h)
+    ctx = m.Context(0)
+    ctx.set_scene(sd)
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for spp, flags in ((4, 0), (28, m.MIRT_FLAG_KERNEL_POOL)):
+        p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, flags=flags)
+        # the pooled kernel's frame against the strip kernel's (itself held against the oracle by the first case and by test_gpu_pt.py)
+        want = oracle.render(sd, p) if flags == 0 else ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, flags=m.MIRT_FLAG_KERNEL_STRIP))
+        ctx.stats()
+        for i in range(150):
+            ctx.render_device(p, out.data_ptr(), out.numel(), stream)
+            if i % 37 == 0 or i == 149:
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want), (spp, i)
+        assert ctx.stats()["launches"] == 150 and ctx.last_kernel().startswith("render_pt_pool" if flags else "render_pt_strip")
+    ctx.close()
+
+
 def test_scene_limits_at_the_boundary(gpu_ctx):
     """include/mirt.h, MIRT_ERR_SCENE_TOO_LARGE: the flat layout holds 96 + 32 n + 48 m + 144 <= 122 880 bytes -- 3 831 spheres
     with one material --, the grid layout at most 4 095 spheres; a scene that fits only the grid layout renders in path-traced

@@ -464,6 +464,7 @@ int mirt_ctx_create(int device, MirtContext** out)
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters * kEventPool);
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool * kDispenserWords);
+    if (e == hipSuccess) e = hipMemset(c->d_work_counter, 0, sizeof(uint32_t) * kEventPool * kDispenserWords);     // see fold_events
     if (e != hipSuccess) {
         const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         mirt_ctx_destroy(c);
@@ -691,6 +692,13 @@ static int fold_events(MirtContext* c)
         c->launches_folded += 1;
         c->last_ms = ms;
     }
+    // Every launch owns the dispenser words of its event slot, and they start at zero: re-zero the used slots HERE, once per fold
+    // (all their kernels have finished: the events above), instead of one to eight memset nodes in front of every kernel -- 3 us
+    // each, in a stream where a 2-spp frame is 16 us and config 2's 0.9 ms.  Synchronous, so that launches on ANY stream come after it.
+    if (c->ev_used > 0) {
+        HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t) * kDispenserWords * c->ev_used, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->ev_used = 0;
     return MIRT_OK;
 }
@@ -891,11 +899,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // The pooled kernel's strips last long at high sample counts (config 3: 9 atomics per microsecond); below 128 spp they do not
     // (three spheres, 1080p, pool forced: 48 / 64 / 100 / 200 spp -13.5 / -8.5 / -2 / +1 % with eight words; RTIOW 16 spp -4.5 %).
     a.spread_units = (a.static_units == 0u && tune.spread_units != 0 && (!pool || p->spp < 128u)) ? 1u : 0u;
-    if (a.spread_units) {
-        for (uint32_t x = 0; x < 8u; ++x)
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(a.work_counter + (size_t)kDispenserStride * x), (int)(launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u), 1, stream));
-    } else if (!(by_pixel && a.static_units))    // units dealt round-robin never touch the dispenser: one memset node less per interactive frame
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.work_counter, (int)launched_waves, 1, stream));
+    a.first_dispensed = launched_waves;          // the words themselves are zero (fold_events): no memset node in front of the kernel
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
 #endif

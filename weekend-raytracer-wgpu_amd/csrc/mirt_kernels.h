@@ -156,6 +156,8 @@ struct RenderArgs {
     uint32_t row_begin, tile_rows, n_parts, part;
     uint32_t out_rows;                     // rows this launch writes
     uint32_t n_units;                      // work units (strips) the dispenser hands out
+    uint32_t first_dispensed;              // the dispenser's words start at ZERO (pre-zeroed per launch slot, no memset node in front of the kernel):
+                                           // units below this one -- one per launched wave -- are taken by wave index (first_unit)
     uint32_t static_units;                 // lane-per-pixel strip kernel: units dealt round-robin instead of dispensed
     uint32_t spread_units;                 // strip-type kernels: units from eight dispenser words (unit u <-> word u mod 8; next_unit_any)
     uint32_t px_groups_log2;               // lane-per-pixel strip kernel: a unit is 64 >> g pixels, their samples dealt to 1 << g groups of lanes

@@ -107,7 +107,7 @@ MIRT_DEV uint32_t abs_row(const RenderArgs& A, uint32_t i)
     return A.row_begin + t * A.tile_rows + i % A.tile_rows;
 }
 
-// The first unit of every wave is its own index in the grid (the host starts the dispenser counter at the
+// The first unit of every wave is its own index in the grid (the dispenser continues at RenderArgs.first_dispensed = the
 // number of waves launched): otherwise all waves of a launch queue up on one atomic address at 14 ns each
 // before any of them has work -- 86 us for 6 144 waves.
 MIRT_DEV uint32_t first_unit() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
@@ -116,7 +116,7 @@ MIRT_DEV uint32_t next_unit(const RenderArgs& A, uint32_t lane)
 {
     uint32_t s = 0;
     if (lane == 0) s = atomicAdd(A.work_counter, 1u);
-    return __builtin_amdgcn_readfirstlane(s);
+    return __builtin_amdgcn_readfirstlane(s) + A.first_dispensed;
 }
 
 // The strip kernels' launches of many small units -- 64 800 units of 32 pixels in a 1 ms launch (config 2) -- run into the rate of ONE
@@ -136,9 +136,10 @@ MIRT_DEV uint32_t next_unit_any(const RenderArgs& A_unused, uint32_t lane)
     for (uint32_t j = 0; j < 8u; ++j) {                    // wave-uniform; kept a loop (unrolled it costs the strip kernels ~45 scalar registers)
         const uint32_t x = (home + j) & 7u;
         const uint32_t share = A.n_units > x ? (A.n_units - x + 7u) >> 3 : 0u;      // units of word x: u = 8 k + x < n_units
-        uint32_t k = 0xffffffffu;
+        const uint32_t taken = A.first_dispensed > x ? (A.first_dispensed - x + 7u) >> 3 : 0u;   // of word x's units, by wave index
+        uint32_t k = 0u;
         if (lane == 0) k = atomicAdd(A.work_counter + (size_t)MIRT_DISPENSER_STRIDE * x, 1u);
-        k = __builtin_amdgcn_readfirstlane(k);
+        k = __builtin_amdgcn_readfirstlane(k) + taken;
         if (k < share) return 8u * k + x;
     }
     return 0xffffffffu;
