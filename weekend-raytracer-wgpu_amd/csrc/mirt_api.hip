@@ -900,6 +900,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // (three spheres, 1080p, pool forced: 48 / 64 / 100 / 200 spp -13.5 / -8.5 / -2 / +1 % with eight words; RTIOW 16 spp -4.5 %).
     a.spread_units = (a.static_units == 0u && tune.spread_units != 0 && (!pool || p->spp < 128u)) ? 1u : 0u;
     a.first_dispensed = launched_waves;          // the words themselves are zero (fold_events): no memset node in front of the kernel
+    for (uint32_t x = 0; x < 8u; ++x) a.disp_taken[x] = launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u;
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
 #endif

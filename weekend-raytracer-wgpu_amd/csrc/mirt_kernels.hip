@@ -136,7 +136,7 @@ MIRT_DEV uint32_t next_unit_any(const RenderArgs& A_unused, uint32_t lane)
     for (uint32_t j = 0; j < 8u; ++j) {                    // wave-uniform; kept a loop (unrolled it costs the strip kernels ~45 scalar registers)
         const uint32_t x = (home + j) & 7u;
         const uint32_t share = A.n_units > x ? (A.n_units - x + 7u) >> 3 : 0u;      // units of word x: u = 8 k + x < n_units
-        const uint32_t taken = A.first_dispensed > x ? (A.first_dispensed - x + 7u) >> 3 : 0u;   // of word x's units, by wave index
+        const uint32_t taken = A.disp_taken[x];                 // of word x's units, those taken by wave index
         uint32_t k = 0u;
         if (lane == 0) k = atomicAdd(A.work_counter + (size_t)MIRT_DISPENSER_STRIDE * x, 1u);
         k = __builtin_amdgcn_readfirstlane(k) + taken;
