@@ -528,6 +528,8 @@ def parse_args(argv):
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="with --gpus 1: form a ONE-rank process group (RCCL; gloo with --dry-run) and take every N > 1 branch -- gather, "
                          "all-reduces, barriers, gather_ms, verification of the gathered frame -- on a box with a single GPU; measures nothing new")
+    ap.add_argument("--preroll-ms", type=float, default=100.0,
+                    help="untimed steps before the warm-up steps until the GPU has been busy this long (clocks settle); 0 = none")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank path on CPU (gloo, pattern renderer); measures nothing")
     return ap.parse_args(argv)
 
@@ -633,6 +635,36 @@ def main(argv=None) -> int:
             sync()
             barrier()
 
+    # Clock pre-roll (untimed, before the W warm-up steps): the GPU's clocks take tens of milliseconds of load to settle after an idle
+    # gap.  Three warm-up steps of a 23 ms kernel cover that; three of config 2's 0.9 ms kernel (or of a 20 us 2-spp frame) do not --
+    # its line read 226 Gsamples/s with the timed region on ramping clocks and 242 after 40 steps.  So: one step to learn its duration
+    # (max over ranks: every rank must run the same number of collectives), then as many as fill PREROLL_S.
+    preroll_steps = 0
+    if not dry and args.preroll_ms > 0:
+        sync()
+        tp = time.perf_counter()
+        frame.step()
+        frame.flush()
+        sync()
+        one = max(time.perf_counter() - tp, 1e-6)
+        if multi:
+            t = torch.tensor([one], dtype=torch.float64, device=torch.device("cuda"))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            one = float(t.item())
+        if multi:                                         # a count every rank agrees on
+            preroll_steps = 1 + min(5000, int(args.preroll_ms * 1e-3 / one))
+            for _ in range(preroll_steps - 1):
+                frame.step()
+        else:                                             # by the clock (`one` of a 20 us frame is mostly the synchronize): batches of ~10 ms
+            preroll_steps = 1
+            batch = max(1, min(256, int(0.01 / one)))
+            while time.perf_counter() - tp < args.preroll_ms * 1e-3 and preroll_steps < 100000:
+                for _ in range(batch):
+                    frame.step()
+                sync()
+                preroll_steps += batch
+        frame.flush()
+        sync()
     for _ in range(args.warmup):
         frame.step()
     frame.flush()
@@ -738,6 +770,7 @@ def main(argv=None) -> int:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_steps": preroll_steps,               # untimed steps before the W warm-up steps (clock pre-roll, --preroll-ms)
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong",
