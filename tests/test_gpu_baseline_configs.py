@@ -51,3 +51,44 @@ def test_config1_plumbing_and_config3_parity_mode(gpu_ctx, oracle):
     got = gpu_ctx.render(m.make_params(1920, 1080, 1000))
     # the oracle's literal loop would take minutes at 1000 spp; K4 says spp >= 21 changes nothing, so 21 is the same image
     assert_images_equal(got, oracle.render(sd, m.make_params(1920, 1080, 21)), "Layer::scene 1080p parity")
+
+
+FULL_SIZE = [  # name, scene, width, height, spp exactly as BASELINE.json names them, chunk of the accumulation, kernel expected
+    ("config2", "single_sphere", 1920, 1080, 100, 25, "render_pt_strip_kernel<false,false,false,true>"),
+    ("config3", "three_spheres", 1920, 1080, 1000, 250, "render_pt_pool_kernel<256,"),
+    ("config4", "earth", 1920, 1080, 1000, 125, "render_pt_pool_kernel<256,"),
+    ("config5", "rtiow_final", 3840, 2160, 4000, 500, "render_pt_pool_kernel<1024,"),
+]
+
+
+@pytest.mark.parametrize("name,scene,w,h,spp,chunk,kernel", FULL_SIZE)
+def test_configs_at_full_size_through_size_independent_properties(gpu_ctx, name, scene, w, h, spp, chunk, kernel):
+    """The BASELINE configurations at FULL size and FULL sample count.  Config 5 -- 3840 x 2160, 4000 samples per pixel, the 8-GPU
+    job -- is out of the oracle's reach (one row takes ten minutes on a host thread; rows at 4 spp are held against it above, a
+    16-row band at 500 spp by bench.py's verified_rows, bands of configs 2-4 at their full sample counts likewise).  What the
+    domain offers at any size: the exact 64-bit radiance sums are ADDITIVE over sample ranges, and the frame does not depend on how
+    it is partitioned.  So: (a) spp / chunk accumulations of `chunk` samples == one of spp, sum for sum; (b) that resolves to the
+    one-shot image; (c) the 8 ranks' tiles of the full job reassemble exactly that image."""
+    sd = scene_data(scene, w, h)
+    gpu_ctx.set_scene(sd)
+    mk = lambda n, **kw: m.make_params(w, h, n, mode=m.MIRT_MODE_PT, num_bounces=8, **kw)   # noqa: E731
+    gpu_ctx.accum_reset(mk(chunk))
+    for _ in range(spp // chunk):
+        gpu_ctx.accum_add(mk(chunk))
+    assert gpu_ctx.accum_samples() == spp
+    in_chunks = gpu_ctx.accum_read(mk(chunk))
+    resolved = gpu_ctx.accum_resolve(mk(chunk))
+    gpu_ctx.accum_reset(mk(spp))
+    gpu_ctx.accum_add(mk(spp))
+    assert np.array_equal(gpu_ctx.accum_read(mk(spp)), in_chunks), name                  # (a)
+    del in_chunks
+    full = gpu_ctx.render(mk(spp))
+    assert gpu_ctx.last_kernel().startswith(kernel), gpu_ctx.last_kernel()               # the schedule bench.py times
+    assert_images_equal(resolved, full, f"{name}: {spp // chunk} x {chunk} spp accumulated vs {spp} spp at once")   # (b)
+    base = mk(spp)
+    parts = np.zeros((8, m.multi_gpu.max_part_rows(base, 8, 4), w, 4), np.uint8)
+    for r in range(8):
+        img = gpu_ctx.render(m.multi_gpu.part_params(base, r, 8, 4))
+        parts[r, :img.shape[0]] = img
+    assert_images_equal(m.multi_gpu.assemble_host(parts, base, 8, 4), full, f"{name}: 8-way tiles at {spp} spp")   # (c)
+    gpu_ctx.accum_reset(m.make_params(8, 8, 1, mode=m.MIRT_MODE_PT))                     # give the sums (199 MB at 4K) back
