@@ -98,7 +98,10 @@ def test_configs_at_full_size_through_size_independent_properties(gpu_ctx, name,
                                                 ("config4", "earth", 1920, 1080, 1000),
                                                 # config 5's frame, every pixel, at the smallest sample count that runs ITS kernel (the grid
                                                 # build of the pooled kernel, from 16 spp): 1.3 x 10^8 samples through the oracle's flat scan
-                                                ("config5 at 16 spp", "rtiow_final", 3840, 2160, 16)])
+                                                ("config5 at 16 spp", "rtiow_final", 3840, 2160, 16),
+                                                # the reference's own default scene (main.rs:527-545: five spheres, two image textures, all
+                                                # four routines), 1080p at its default max_samples_per_pixel (mod.rs:605-613)
+                                                ("main.rs scene at 128 spp", "main_rs_scene", 1920, 1080, 128)])
 def test_complete_frames_at_the_full_sample_count_against_the_oracle(gpu_ctx, oracle, name, scene, w, h, spp):
     """Configs 2-4 exactly as BASELINE names them (and config 5's 8.3-megapixel frame at 16 samples), the COMPLETE frame: every pixel's exact 64-bit radiance sums from the GPU
     against the oracle's -- 2 x 10^9 samples of config 3, about 20 s of oracle time on the GPU box's host cores (bench.py's
