@@ -127,3 +127,23 @@ def test_complete_frames_at_the_full_sample_count_against_the_oracle(gpu_ctx, or
         pytest.skip(f"{name}: the four probe rows are equal; a complete-frame oracle pass would take ~{projected:.0f} s on this host")
     want = oracle.render_pt_sums(sd, p)
     assert np.array_equal(got, want), f"{name}: {int((got != want).any(-1).sum())} of {w * h} pixels differ"
+
+
+def test_the_reference_render_loop_at_its_operating_point_complete_frame(gpu_ctx, oracle):
+    """What the reference's window shows after its default accumulation: main.rs's scene, 1920 x 1080, 2 samples per pixel and frame
+    (mod.rs:605-613) up to max_samples_per_pixel = 128, every frame seeded as Raytracer::render_frame seeds it (ONE stream per pixel
+    and frame: MirtParams.frame_spp = 2; frame_number starts at 1, mod.rs:284).  64 accumulate calls of 2 samples on the GPU -- the
+    reference's own loop shape -- against ONE oracle pass over all 128: the exact sums of every pixel, then the resolved image."""
+    w, h, n, total = 1920, 1080, 2, 128
+    sd = scene_data("main_rs_scene", w, h)
+    gpu_ctx.set_scene(sd)
+    mk = lambda spp: m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=n)   # noqa: E731
+    gpu_ctx.accum_reset(mk(n))
+    for _ in range(total // n):
+        gpu_ctx.accum_add(mk(n))
+    assert gpu_ctx.accum_samples() == total and gpu_ctx.last_kernel().startswith("render_pt_strip_kernel<")
+    got = gpu_ctx.accum_read(mk(n))
+    want = oracle.render_pt_sums(sd, mk(total))
+    assert np.array_equal(got, want), f"{int((got != want).any(-1).sum())} of {w * h} pixels differ"
+    assert_images_equal(gpu_ctx.accum_resolve(mk(n)), oracle.render(sd, mk(total)), "resolved frame")
+    gpu_ctx.accum_reset(m.make_params(8, 8, 1, mode=m.MIRT_MODE_PT))
