@@ -58,6 +58,9 @@ COLS = ["valu_fp", "valu_seed", "valu_int", "valu_cmp_select", "valu_convert", "
 
 
 def main() -> int:
+    if len(sys.argv) > 1 and sys.argv[1].startswith("-"):
+        print("usage: tools/isa_mix.py [TAG]   -> profiles/TAG_isa_mix.md (static instruction mix of the probe kernels; builds them first)")
+        return 0
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     out = CSRC / "build" / "probes"
     out.mkdir(parents=True, exist_ok=True)
