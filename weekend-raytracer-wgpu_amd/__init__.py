@@ -14,5 +14,5 @@ from .context import Context, SceneData, make_params, params_out_row_index, para
 from .raytracer import *  # noqa: F401,F403
 from . import scenes
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
 from . import multi_gpu
