@@ -124,7 +124,7 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     if (small.size() < mirt::kGridMinSpheres / 2 || big.size() > 64) return blob;
     // cell = 2.5 median radii (a binned sphere of up to 4 median radii spans at most 5 cells per axis).  Measured on RTIOW, 1080p x 128 spp,
     // records stored once per sphere: 4 -> 14.31 ms, 3.5 -> 13.95, 3 -> 13.35, 2.75 -> 13.38, 2.5 -> 13.18, 2.25 -> 13.11, 2 -> 19.7 (the cell
-    // table outgrows LDS: 128-slot pools); fewer tests per ray against more cells per ray (profiles/r03_c5_cell_size.txt)
+    // table outgrows LDS: 128-slot pools); fewer tests per ray against more cells per ray (profiles/r03_c5_ab.txt blocks 4 and 7)
     const double cell_factor = cell_factor_knob > 0.0 ? cell_factor_knob : 2.5;   // mirt_ctx_set_scene passes the factor it settles on
     double cell = cell_factor * r_med;
     uint32_t dims[3];
