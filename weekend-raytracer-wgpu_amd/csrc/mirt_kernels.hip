@@ -1,13 +1,15 @@
 // mirt_kernels.hip — the gfx950 (CDNA4, wave64) kernels of the per-pixel ray-trace path.
 //
-// ONE WORKITEM PER PIXEL-SAMPLE everywhere.  The scene (camera, sphere list, material table) is
+// A LANE CARRIES ONE PIXEL-SAMPLE AT A TIME.  The scene (camera, sphere list, material table) is
 // staged once per block into LDS; all lanes read the same sphere at the same time, which LDS
 // serves as a broadcast.  Wave ballots give the uniform loop exits and resolve the sequential
 // semantics of the reference's sample loop.
 //
-//   render_parity_kernel   reference src/raytracer/layer.rs:264-444 semantics, bit-faithful, no fma.
-//   render_pt_strip_kernel behaviours of src/raytracer/raytracer.wgsl:50-521; a wave owns a strip of
-//                          pixels, its 64 lanes take samples lane, lane+64, …  (small spp, huge scenes).
+//   render_parity_kernel   reference src/raytracer/layer.rs:264-444 semantics, bit-faithful, no fma.  Two schedules
+//                          (BY_PIXEL): lane = pixel below 64 samples per pixel (the reference runs 2), lane = sample above.
+//   render_pt_strip_kernel behaviours of src/raytracer/raytracer.wgsl:50-521; a wave owns a unit of pixels.  BY_PIXEL:
+//                          lane = pixel, every lane walks its pixel's samples (few samples per pixel; any count in scenes
+//                          with one shading routine); else the 64 lanes take samples lane, lane+64, … of one pixel.
 //   render_pt_pool_kernel  the same arithmetic, scheduled differently: every wave keeps a pool of
 //                          paths in LDS, queued by the shading routine they wait for, and always
 //                          runs ONE routine on up to 64 of them — the material switch no longer
