@@ -232,7 +232,10 @@ def test_missing_material_id_and_every_material(gpu_ctx, oracle):
     assert all(n > 0 for n in gs["scatter"]), gs["scatter"]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MIRT_FUZZ_SEEDS", "8"))))     # deeper runs: MIRT_FUZZ_SEEDS=300
+_FUZZ0 = int(os.environ.get("MIRT_FUZZ_FIRST_SEED", "0"))        # soak runs beyond the seeds of earlier soaks: MIRT_FUZZ_FIRST_SEED=1000
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ0, _FUZZ0 + int(os.environ.get("MIRT_FUZZ_SEEDS", "8"))))     # deeper runs: MIRT_FUZZ_SEEDS=300
 def test_random_scenes_materials_and_cameras(gpu_ctx, oracle, seed):
     """Fuzz of the path-traced mode: random sphere soups (overlapping, nested, behind the camera, huge), random
     material tables (every routine incl. the missing-material one, random fuzz / refraction index, 1x1 and
@@ -633,7 +636,7 @@ def test_raytracer_render_frame_with_the_reference_stream(oracle):
     rt.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MIRT_GRID_FUZZ_SEEDS", "10"))))      # deeper runs: MIRT_GRID_FUZZ_SEEDS=60
+@pytest.mark.parametrize("seed", range(_FUZZ0, _FUZZ0 + int(os.environ.get("MIRT_GRID_FUZZ_SEEDS", "10"))))      # deeper runs: MIRT_GRID_FUZZ_SEEDS=60
 def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
     """Random soups of 32-700 spheres (0-3 big ones besides the ground, random cell sizes through the radii, random
     cameras with and without aperture, 2-8 bounces): the pool kernel's grid build -- several pool geometries occur
