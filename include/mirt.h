@@ -249,9 +249,11 @@ typedef enum MirtStatus {
      *   flat layout (every mode and flag): 96 + 32 * n_spheres + 48 * n_materials + 144 <= 122 880 bytes
      *       -- e.g. 3 831 spheres with one material;
      *   grid layout (MIRT_MODE_PT only, scenes of >= 32 spheres of which at most 64 exceed 4 median radii): n_spheres <= 4 095
-     *       (12-bit sphere ids in a path's state word), <= 8 192 cells (the host coarsens the cells to stay below), <= 65 535
-     *       cell entries, and 240 + blob <= 122 880 bytes with blob ~ 17 * n_spheres + 4 * cells + 2 * entries.  Grids with a
-     *       dimension above 1 024 cells (10-bit cell coordinates) run the strip kernel instead of the pooled one.
+     *       (12-bit sphere ids in a path's state word), <= 8 192 cells and <= 65 535 cell entries (the host starts at a cell of
+     *       2.5 median radii and coarsens it, x 1.26 per step up to 4, while either limit is exceeded or the blob would cost the
+     *       pooled kernel its 152-slot geometry), and 240 + blob <= 122 880 bytes with blob ~ 17 * n_spheres + 4 * cells +
+     *       2 * entries.  Grids with a dimension above 1 024 cells (10-bit cell coordinates) run the strip kernel instead of
+     *       the pooled one.  mirt_grid_plan() answers "which grid would this scene get" without a device.
      * A scene that fits ONLY the grid layout renders in path-traced mode with default flags; a render call in parity mode, or
      * with MIRT_FLAG_COUNT_WORK without MIRT_FLAG_COUNT_GRID, or with MIRT_FLAG_NO_GRID, returns this code. */
     MIRT_ERR_SCENE_TOO_LARGE      = -18,
@@ -300,6 +302,21 @@ float mirt_radians_to_degrees(float radians);
 uint32_t mirt_params_out_rows(const MirtParams* params);
 /* Absolute image row of compact output row `i` (UINT32_MAX if out of range). */
 uint32_t mirt_params_out_row_index(const MirtParams* params, uint32_t i);
+
+/* The uniform grid mirt_ctx_set_scene would build over these spheres (many-sphere scenes, path-traced mode): HOST-ONLY -- no
+ * device, no context.  `lds_bytes_per_block` = LDS a workgroup may use (0 = gfx950's 163 840).  cell_factor = the cell edge in
+ * median radii the coarsening rule settles on (0 = no grid: fewer than 32 spheres, nothing small enough to bin, more than 64
+ * big spheres, or more than 65 535 cell entries even at the coarsest cell); pool_slots = path slots per wave the pooled kernel's
+ * grid build would run beside that blob (0 = it does not fit: strip kernel). */
+typedef struct MirtGridPlan {
+    float    cell_factor;
+    uint32_t blob_bytes;
+    uint32_t n_cells;
+    uint32_t n_entries;
+    uint32_t n_big;
+    uint32_t pool_slots;
+} MirtGridPlan;
+int mirt_grid_plan(const MirtSphere* spheres, uint32_t n_spheres, uint64_t lds_bytes_per_block, MirtGridPlan* out);
 
 /* Create / destroy a context on HIP device `device` (ordinal as seen by this process). */
 int  mirt_ctx_create(int device, MirtContext** out);

@@ -152,6 +152,17 @@ pub struct MirtParams {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
+pub struct MirtGridPlan {
+    pub cell_factor: f32,
+    pub blob_bytes: u32,
+    pub n_cells: u32,
+    pub n_entries: u32,
+    pub n_big: u32,
+    pub pool_slots: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct MirtStats {
     pub kernel_ms: f64,
     pub kernel_ms_total: f64,
@@ -187,6 +198,7 @@ extern "C" {
     pub fn mirt_radians_to_degrees(radians: f32) -> f32;
     pub fn mirt_params_out_rows(params: *const MirtParams) -> u32;
     pub fn mirt_params_out_row_index(params: *const MirtParams, i: u32) -> u32;
+    pub fn mirt_grid_plan(spheres: *const MirtSphere, n_spheres: u32, lds_bytes_per_block: u64, out: *mut MirtGridPlan) -> c_int;
     pub fn mirt_ctx_create(device: c_int, out: *mut *mut MirtContext) -> c_int;
     pub fn mirt_ctx_destroy(ctx: *mut MirtContext);
     pub fn mirt_ctx_set_scene(ctx: *mut MirtContext, scene: *const MirtScene) -> c_int;

@@ -72,3 +72,20 @@ def assert_images_equal(a: np.ndarray, b: np.ndarray, what: str = "") -> None:
         ys, xs = np.nonzero(diff)
         first = [(int(x), int(y), a[y, x].tolist(), b[y, x].tolist()) for y, x in list(zip(ys, xs))[:5]]
         raise AssertionError(f"{what}: {int(diff.sum())}/{diff.size} pixels differ (u8-exact required); first: {first}")
+
+
+def full_frame_bands(h: int, seconds_per_row_thread: float, cores: int, budget_seconds: float, band: int = 16):
+    """Row ranges [first, last) the complete-frame test compares: the whole frame as ONE range when the oracle's pass fits the
+    budget (rows are spread over half the host's cores, as measured on the GPU box), else as many `band`-row bands as fit --
+    at least one --, evenly spread from the first rows to the last."""
+    par = max(1.0, cores * 0.5)
+    if seconds_per_row_thread * h / par <= budget_seconds:
+        return [(0, h)]
+    band = min(band, h)
+    per_band = seconds_per_row_thread * band / min(par, band)          # a band keeps at most `band` threads busy
+    n = max(1, min(int(budget_seconds / max(per_band, 1e-9)), h // band))
+    if n == 1:
+        first = max(0, h // 2 - band // 2)
+        return [(first, first + band)]
+    starts = [round(i * (h - band) / (n - 1)) for i in range(n)]
+    return [(s0, s0 + band) for s0 in sorted(set(starts))]

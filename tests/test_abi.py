@@ -79,3 +79,60 @@ def test_product_does_not_reference_the_oracle():
     for path in list(pkg.rglob("*.py")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.cpp")) + list(pkg.rglob("Makefile")):
         text = path.read_text()
         assert "oracle" not in text.lower(), f"{path} mentions the oracle"
+
+
+# ---- mirt_grid_plan: the grid mirt_ctx_set_scene would build, host-only (no device) ----
+
+def _grid_plan(spheres, lds=0):
+    arr = (_abi.MirtSphere * len(spheres))(*spheres)
+    out = _abi.MirtGridPlan()
+    assert m.lib().mirt_grid_plan(C.cast(arr, C.c_void_p), len(spheres), lds, C.byref(out)) == 0, m.lib().mirt_last_error()
+    return out
+
+
+def bimodal_soup(seed=0, n_small=1300, n_medium=1100, r=0.05, extent_radii=20.0):
+    """A soup whose spheres are either r or 3.9 r (just under the 4-median-radii limit of the grid): at the default cell of 2.5
+    median radii a medium sphere spans 4-5 cells per axis and the lists overflow their 16-bit index; at 4 they do not."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    rs = np.concatenate([np.full(n_small, r), np.full(n_medium, 3.9 * r)]).astype(np.float32)
+    cs = rng.uniform(-extent_radii * r, extent_radii * r, (n_small + n_medium, 3)).astype(np.float32)
+    return cs, rs
+
+
+def _entries_at(cs, rs, factor):
+    """Cell entries the binning of csrc/mirt_api.hip::build_grid produces at `factor` median radii (same arithmetic, in numpy)."""
+    import numpy as np
+    cs, rs = cs.astype(np.float64), rs.astype(np.float64)
+    cell = factor * np.sort(rs)[len(rs) // 2]
+    lo, hi = (cs - rs[:, None]).min(0), (cs + rs[:, None]).max(0)
+    while np.prod(np.maximum(1, np.ceil((hi - lo) / cell + 1e-6))) > 8192:
+        cell *= 1.26
+    dims = np.maximum(1, np.ceil((hi - lo) / cell + 1e-6)).astype(int)
+    eps = 1e-3 * cell
+    c0 = np.clip(np.floor((cs - rs[:, None] - eps - lo) / cell), 0, dims - 1)
+    c1 = np.clip(np.floor((cs + rs[:, None] + eps - lo) / cell), 0, dims - 1)
+    return int(np.prod(c1 - c0 + 1, axis=1).sum())
+
+
+def test_grid_plan_of_the_rtiow_scene():
+    scene, _ = m.scenes.rtiow_final()
+    g = _grid_plan([s.to_c() for s in scene.spheres])
+    assert g.cell_factor == 2.5 and g.n_big == 4 and g.pool_slots == 152            # ground + the three r = 1 spheres stay outside the grid
+    assert 0 < g.blob_bytes < 24 * 1024 and g.n_cells <= 8192 and 0 < g.n_entries < 65536
+    assert _grid_plan([s.to_c() for s in scene.spheres[:20]]).cell_factor == 0.0      # fewer than 32 spheres: no grid
+
+
+def test_grid_plan_coarsens_past_an_entry_overflow():
+    """Round 3's finer default cell must not cost a scene the grid it had at round 2's cell of 4: when the lists overflow
+    65 535 entries the builder retries coarser (x 1.26 per step, capped at 4.0 -- never 5.0) instead of giving up."""
+    cs, rs = bimodal_soup()
+    assert _entries_at(cs, rs, 2.5) > 65535 > _entries_at(cs, rs, 4.0)
+    g = _grid_plan([m.Sphere.new(tuple(float(x) for x in c), float(r), 0).to_c() for c, r in zip(cs, rs)])
+    assert g.cell_factor == 4.0 and g.n_entries == _entries_at(cs, rs, 4.0)
+    assert 0 < g.blob_bytes <= 120 * 1024 - 240                                         # fits the grid layout (include/mirt.h)
+    # spheres of ONE size coarsen only as far as LDS asks: never past 4.0
+    import numpy as np
+    rng = np.random.default_rng(5)
+    uni = [m.Sphere.new(tuple(float(x) for x in rng.uniform(-3, 3, 3)), 0.05, 0).to_c() for _ in range(3000)]
+    assert 2.5 <= _grid_plan(uni).cell_factor <= 4.0

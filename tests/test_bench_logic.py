@@ -154,3 +154,80 @@ def test_the_rehearsal_of_the_n_rank_branches_runs_without_a_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["frames_verified"] and d["verified_frame"] == "gathered on rank 0" and d["backend"] == "gloo" and d["gather_ms"] > 0.0
+
+
+def test_verify_rows_falls_back_to_rank0s_own_render_when_the_oracle_is_out_of_reach(monkeypatch):
+    """BASELINE configs[4] -- 3840 x 2160 x 4000 spp, the one job DEFINED on 8 GPUs -- costs the oracle ten minutes per row.  Its
+    line must not say "skipped": verify_rows then compares the probe bands of the gathered frame with rank 0's own single-GPU render
+    of those rows (partition + gather + de-interleave at full size) and names that checker in every entry."""
+    import numpy as np
+    cfg = dict(bench.CONFIGS["5"], spp=4000)
+    w, h = cfg["width"], cfg["height"]
+    frame = np.zeros((h, 8, 4), np.uint8)                       # 8 columns stand in for 3840: verify_rows only slices rows
+    frame[..., 0] = (np.arange(h) % 251)[:, None]
+    calls = []
+
+    def self_rows(first, last):
+        calls.append((first, last))
+        return frame[first:last].copy()
+
+    class _NoOracle:                                             # the oracle must not be asked for a row
+        @staticmethod
+        def render(*a, **k):
+            raise AssertionError("the oracle was called for a workload it cannot afford")
+    import sys as _sys
+    monkeypatch.setitem(_sys.modules, "oracle_binding", _NoOracle)
+    monkeypatch.setattr(bench, "host_cores", lambda: 256)       # the GPU box's host
+    # cpu_msamples_per_s as the N = 1 line measured it for RTIOW: ~6 Msamples/s on all cores -> ~650 s per row and thread
+    rows = bench.verify_rows(None, None, cfg, frame, cpu_msamples_per_s=6.0, self_rows=self_rows, against="auto")
+    assert len(rows) == len(bench.VERIFY_ROWS[2160]) == len(calls)
+    assert all(r["against"] == "rank0_single_gpu_render" and r["equal"] and r["spp"] == 4000 and "skipped" not in r for r in rows)
+    assert all("oracle row" in r["note"] for r in rows)
+    # a wrong row in the gathered frame is caught
+    bad = frame.copy()
+    bad[1081, 3, 1] ^= 1
+    rows = bench.verify_rows(None, None, cfg, bad, cpu_msamples_per_s=6.0, self_rows=self_rows, against="auto")
+    assert [r["equal"] for r in rows].count(False) == 1 and [r for r in rows if not r["equal"]][0]["rows_equal"] == 15
+    # forced oracle on that workload still reports the skip (and says which checker skipped); forced self never needs the rate
+    rows = bench.verify_rows(None, None, cfg, frame, cpu_msamples_per_s=6.0, self_rows=self_rows, against="oracle")
+    assert rows == [dict(rows[0])] and rows[0]["against"] == "oracle" and "skipped" in rows[0]
+    rows = bench.verify_rows(None, None, cfg, frame, self_rows=self_rows, against="rank0_single_gpu_render")
+    assert all(r["against"] == "rank0_single_gpu_render" and r["equal"] for r in rows)
+    # an affordable workload keeps the oracle (here: the dry run's pattern stands in for it)
+    cfg3 = dict(bench.CONFIGS["3"])
+    f3 = bench.pattern_rows(range(1080), 16)
+    rows = bench.verify_rows(None, None, cfg3, f3, oracle_rows=lambda a, b: bench.pattern_rows(range(a, b), 16), self_rows=self_rows, against="auto")
+    assert len(rows) == 5 and all(r["against"] == "oracle" and r["equal"] for r in rows)
+
+
+def test_the_dry_run_takes_the_self_render_branch_of_the_verification():
+    """`bench.py --gpus 2 --dry-run --verify-against self`: the gathered frame's probe bands against bands rank 0 renders itself through
+    row_begin / row_end (the pattern context here, the GPU in a real run)."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--verify-against", "self"],
+                       env=_bare_env(), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["frames_verified"] and len(d["verified_rows"]) >= 3
+    assert all(v["against"] == "rank0_single_gpu_render" and v["equal"] for v in d["verified_rows"])
+    # ... and the one-rank rehearsal too
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run", "--rehearse-collectives", "--steps", "1", "--warmup", "0", "--verify-against", "self"],
+                       env=_bare_env(), capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert all(v["against"] == "rank0_single_gpu_render" and v["equal"] for v in d["verified_rows"])
+
+
+def test_the_complete_frame_test_never_compares_nothing():
+    """tests/test_gpu_baseline_configs.py::test_complete_frames_...: the whole frame when the oracle's pass fits the budget, else as
+    many 16-row bands as do -- at least one -- spread over the frame."""
+    from helpers import full_frame_bands
+    assert full_frame_bands(1080, 0.9, 256, 120.0) == [(0, 1080)]                       # the GPU box: 20 s for config 3
+    slow = full_frame_bands(1080, 20.0, 8, 120.0)                                       # this container
+    assert len(slow) == 1 and slow[0][1] - slow[0][0] == 16 and slow[0][0] < 540 < slow[0][1]
+    hopeless = full_frame_bands(1080, 5000.0, 2, 120.0)
+    assert len(hopeless) == 1 and hopeless[0][1] - hopeless[0][0] == 16                 # never zero
+    mid = full_frame_bands(2160, 5.0, 16, 120.0)
+    assert 2 <= len(mid) < 2160 // 16 and mid[0] == (0, 16) and mid[-1] == (2144, 2160)
+    assert all(b - a == 16 for a, b in mid) and all(mid[i][1] <= mid[i + 1][0] for i in range(len(mid) - 1))
+    assert full_frame_bands(8, 1000.0, 4, 1.0) == [(0, 8)]                              # a frame smaller than a band

@@ -338,9 +338,10 @@ def _soup(n_small, n_large, spread):
 
 
 def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
-    """A launch takes its work units from dispenser words that belong to its event slot and start at zero (no memset node in
-    front of the kernel); the slots are re-zeroed when the pool of 64 is folded.  150 dispensed launches in a row -- the fold
-    happens inside mirt_ctx_render_device, twice -- must all produce the oracle's frame, in the strip and in the pooled kernel."""
+    """A launch takes its work units from dispenser words that belong to its slot of the event ring and start at zero (no memset
+    node in front of the kernel); a slot's words are re-zeroed behind the kernel that used them, on the context's own stream, and
+    the slot's next user -- 64 launches later -- waits for that.  150 dispensed launches in a row -- the ring wraps twice inside
+    mirt_ctx_render_device -- must all produce the oracle's frame, in the strip and in the pooled kernel."""
     import torch
     w, h = 800, 400                  # 20 000 units of 16 pixels: more than the waves of a launch, so most units come from the dispenser
     sd = scene_data("three_spheres", w, h)
@@ -359,6 +360,49 @@ def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy(), want), (spp, i)
         assert ctx.stats()["launches"] == 150 and ctx.last_kernel().startswith("render_pt_pool" if flags else "render_pt_strip")
+    ctx.close()
+
+
+def test_the_event_ring_wraps_with_launches_on_two_streams(oracle):
+    """The ring of 64 launch slots with launches of ONE context alternating between two caller streams (they overlap on the GPU):
+    200 launches -- three wraps -- of two different dispensed workloads, no synchronisation in between except every 61st pair, and
+    every frame checked.  A slot handed to a new launch before its previous user had finished, or before its dispenser words were
+    zero again, would skip units (pixels left at the 0xAB fill) or hand one out twice."""
+    import torch
+    w, h = 640, 360
+    sd = scene_data("three_spheres", w, h)
+    ctx = m.Context(0)
+    ctx.set_scene(sd)
+    pa = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3)                                   # strip kernel, lane = pixel, dispensed units
+    pb = m.make_params(w, h, 32, mode=m.MIRT_MODE_PT, seed=4, flags=m.MIRT_FLAG_KERNEL_POOL)   # pooled kernel
+    want_a, want_b = oracle.render(sd, pa), oracle.render(sd, pb)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    b = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    ctx.stats()
+    for i in range(100):
+        check = i % 61 == 0 or i == 99
+        if check:
+            torch.cuda.synchronize()
+            a.fill_(0xAB)
+            b.fill_(0xAB)
+            torch.cuda.synchronize()
+        ctx.render_device(pa, a.data_ptr(), a.numel(), s1.cuda_stream)
+        ctx.render_device(pb, b.data_ptr(), b.numel(), s2.cuda_stream)
+        if check:
+            torch.cuda.synchronize()
+            assert np.array_equal(a.cpu().numpy(), want_a), ("stream 1", i)
+            assert np.array_equal(b.cpu().numpy(), want_b), ("stream 2", i)
+    st = ctx.stats()
+    assert st["launches"] == 200 and st["kernel_ms_total"] > 0.0
+    # a statically dealt launch (2 spp: the reference's interactive frame) between dispensed ones leaves its slot's words alone
+    p2 = m.make_params(w, h, 2, mode=m.MIRT_MODE_PT)
+    want2 = oracle.render(sd, p2)
+    for i in range(70):
+        ctx.render_device(p2 if i % 2 else pa, a.data_ptr(), a.numel(), s1.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), want2)
+    assert ctx.stats()["launches"] == 70
     ctx.close()
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import weekend_raytracer_wgpu_amd as m
-from helpers import assert_images_equal, layer_scene_data, scene_data
+from helpers import assert_images_equal, full_frame_bands, layer_scene_data, scene_data
 
 pytestmark = pytest.mark.gpu
 
@@ -105,8 +105,10 @@ def test_configs_at_full_size_through_size_independent_properties(gpu_ctx, name,
 def test_complete_frames_at_the_full_sample_count_against_the_oracle(gpu_ctx, oracle, name, scene, w, h, spp):
     """Configs 2-4 exactly as BASELINE names them (and config 5's 8.3-megapixel frame at 16 samples), the COMPLETE frame: every pixel's exact 64-bit radiance sums from the GPU
     against the oracle's -- 2 x 10^9 samples of config 3, about 20 s of oracle time on the GPU box's host cores (bench.py's
-    verified_rows holds 80 of the 1080 rows; this is all of them).  Skipped on a host where the oracle's pass would take more
-    than two minutes (projected from four rows)."""
+    verified_rows holds 80 of the 1080 rows; this is all of them).  On a host too slow for the whole pass inside two minutes
+    (projected from four probe rows) the test does NOT skip: it compares as many 16-row bands as fit that budget, spread over
+    the frame, at the full sample count -- never fewer than one band -- and says in its report how many rows it held."""
+    import os
     import time
     sd = scene_data(scene, w, h)
     gpu_ctx.set_scene(sd)
@@ -121,12 +123,16 @@ def test_complete_frames_at_the_full_sample_count_against_the_oracle(gpu_ctx, or
         band = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, row_begin=rb, row_end=rb + 1)
         assert np.array_equal(got[rb:rb + 1], oracle.render_pt_sums(sd, band, n_threads=1)), f"{name}: row {rb}"
     per_row_thread = (time.perf_counter() - t0) / len(probe_rows)
-    import os
-    projected = per_row_thread * h / max(1, (os.cpu_count() or 1) * 0.5)
-    if projected > 120.0:
-        pytest.skip(f"{name}: the four probe rows are equal; a complete-frame oracle pass would take ~{projected:.0f} s on this host")
-    want = oracle.render_pt_sums(sd, p)
-    assert np.array_equal(got, want), f"{name}: {int((got != want).any(-1).sum())} of {w * h} pixels differ"
+    budget = float(os.environ.get("MIRT_FULL_FRAME_BUDGET_S", "120"))
+    bands = full_frame_bands(h, per_row_thread, os.cpu_count() or 1, budget)
+    for first, last in bands:
+        band = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, row_begin=first, row_end=last)
+        want = oracle.render_pt_sums(sd, band)
+        assert np.array_equal(got[first:last], want), f"{name}: rows {first}..{last}: {int((got[first:last] != want).any(-1).sum())} pixels differ"
+    held = sum(b - a for a, b in bands)
+    assert held >= min(16, h)
+    if held < h:                                     # visible with -rA / in the junit report; the test still PASSES on what it compared
+        print(f"{name}: slow host ({per_row_thread:.2f} s per row and thread): {held} of {h} rows compared in {len(bands)} bands")
 
 
 def test_the_reference_render_loop_at_its_operating_point_complete_frame(gpu_ctx, oracle):

@@ -67,3 +67,23 @@ def test_the_n_rank_branches_run_over_rccl_on_one_gpu():
     assert len(d["verified_rows"]) >= 4 and all(v["equal"] for v in d["verified_rows"])
     assert d["roofline"]["scope"].startswith("rank 0's share") and d["roofline"]["achieved_whole_job"] > 0.0
     assert "cpu_baseline" not in d and len(d["roofline"]["kernel_ms_per_rank"]) == 1
+    assert all(v["against"] == "oracle" for v in d["verified_rows"])
+    assert d["verified_whole_frame"]["equal"] is True and d["verified_whole_frame"]["rows"] == [0, 1080]
+
+
+def test_the_8_gpu_headline_job_verifies_its_gathered_frame_without_the_oracle():
+    """BASELINE configs[4] exactly as named -- 3840 x 2160 x 4000 spp -- through the N-rank branches (one-rank RCCL group): one oracle row
+    of it takes ten minutes, so `verified_rows` must come from rank 0's own single-GPU render of the probe bands (not "skipped"), plus
+    the complete gathered frame against rank 0's render of the whole frame."""
+    d = _bench("--config", "5", "--spp", "4000", "--rehearse-collectives", "--steps", "1", "--warmup", "0", "--preroll-ms", "0")
+    assert d["config"]["spp"] == 4000 and d["config"]["width"] == 3840
+    rows = d["verified_rows"]
+    assert len(rows) >= 3 and all("skipped" not in v and v["equal"] and v["against"] == "rank0_single_gpu_render" and v["spp"] == 4000 for v in rows)
+    assert d["verified_whole_frame"]["equal"] is True and d["verified_whole_frame"]["rows"] == [0, 2160]
+
+
+def test_cpu_baseline_is_a_best_of_n():
+    d = _bench("--config", "2", "--steps", "2", "--warmup", "1")
+    cb = d["cpu_baseline"]
+    assert cb["repeats"] >= 3 and cb["min"] <= cb["median"] <= cb["value"] and cb["omp"]["OMP_PROC_BIND"]
+    assert all(v["against"] == "oracle" and v["equal"] for v in d["verified_rows"])

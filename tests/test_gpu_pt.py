@@ -633,6 +633,13 @@ def test_raytracer_render_frame_with_the_reference_stream(oracle):
         want = oracle.render(sd2, m.make_params(64, 40, k, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2, frame_begin=5))
         assert_images_equal(img, want, f"after the camera move, {k} spp")
     assert rt.frame_number == 8
+    # the one-shot render() does NOT inherit the progressive loop's frame count: frames 1..4 by default (a fresh reference Raytracer),
+    # whatever render_frame / set_render_params calls came before; frame_begin = frame_number - 1 asks for the accumulation the loop
+    # would start now
+    fresh = oracle.render(sd2, m.make_params(64, 40, 8, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2, frame_begin=0))
+    assert_images_equal(rt.render(), fresh, "render() after a session = frames 1..4")
+    now = oracle.render(sd2, m.make_params(64, 40, 8, mode=m.MIRT_MODE_PT, num_bounces=8, frame_spp=2, frame_begin=7))
+    assert_images_equal(rt.render(frame_begin=rt.frame_number - 1), now, "render(frame_begin=frame_number - 1)")
     rt.close()
 
 

@@ -20,7 +20,7 @@ def test_every_header_symbol_is_declared():
 
 def test_struct_fields_match_the_ctypes_mirror():
     for name in ("MirtSphere", "MirtTextureDescriptor", "MirtMaterial", "MirtGpuCamera", "MirtSkyState", "MirtCamera",
-                 "MirtSamplingParams", "MirtScene", "MirtParams", "MirtStats"):
+                 "MirtSamplingParams", "MirtScene", "MirtParams", "MirtStats", "MirtGridPlan"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, RS, re.S).group(1)
         rust_fields = re.findall(r"pub (\w+):", body)
         py_fields = [f[0] for f in getattr(_abi, name)._fields_]
@@ -81,7 +81,7 @@ def test_struct_field_types_match_the_ctypes_mirror():
     """Names and order are checked above; this compares every field's TYPE (u32 / u64 / f32 / f64 / arrays / nested structs /
     pointers) -- with #[repr(C)] that fixes the layout, which the ctypes mirror's layout tests pin against the header."""
     for name in ("MirtSphere", "MirtTextureDescriptor", "MirtMaterial", "MirtGpuCamera", "MirtSkyState", "MirtCamera",
-                 "MirtSamplingParams", "MirtScene", "MirtParams", "MirtStats"):
+                 "MirtSamplingParams", "MirtScene", "MirtParams", "MirtStats", "MirtGridPlan"):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, RS, re.S).group(1)
         rust = dict(re.findall(r"pub (\w+): ([^,\n]+),", body))
         assert re.search(r"#\[repr\(C\)\]\s*(#\[derive\([^\]]*\)\]\s*)?pub struct %s " % name, RS), f"{name} is not #[repr(C)]"

@@ -105,6 +105,11 @@ class MirtParams(C.Structure):
                 ("sample_begin", C.c_uint32), ("frame_spp", C.c_uint32), ("frame_begin", C.c_uint32)]
 
 
+class MirtGridPlan(C.Structure):
+    _fields_ = [("cell_factor", C.c_float), ("blob_bytes", C.c_uint32), ("n_cells", C.c_uint32), ("n_entries", C.c_uint32),
+                ("n_big", C.c_uint32), ("pool_slots", C.c_uint32)]
+
+
 class MirtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("kernel_ms_total", C.c_double), ("launches", C.c_uint64),
                 ("samples", C.c_uint64), ("rays", C.c_uint64),
@@ -138,6 +143,7 @@ SYMBOLS = {
     "mirt_radians_to_degrees": (C.c_float, [C.c_float]),
     "mirt_params_out_rows": (C.c_uint32, [_P(MirtParams)]),
     "mirt_params_out_row_index": (C.c_uint32, [_P(MirtParams), C.c_uint32]),
+    "mirt_grid_plan": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, _P(MirtGridPlan)]),
     "mirt_ctx_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
     "mirt_ctx_destroy": (None, [C.c_void_p]),
     "mirt_ctx_set_scene": (C.c_int, [C.c_void_p, _P(MirtScene)]),

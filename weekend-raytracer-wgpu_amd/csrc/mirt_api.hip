@@ -97,10 +97,12 @@ V3 add3(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
 V3 sub3(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
 
 // Build the uniform grid of mirt_kernels.h over the spheres of a many-sphere scene.  Returns an empty
-// blob when a grid would not help (few spheres, or nothing small enough to bin).
-std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double cell_factor_knob, double big_factor_knob)
+// blob when a grid would not help (few spheres, or nothing small enough to bin) -- or when THIS cell size lists more
+// than 65 535 items (`*overflow` = true: a coarser cell may still work, mirt_ctx_set_scene retries).
+std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double cell_factor_knob, double big_factor_knob, bool* overflow = nullptr)
 {
     std::vector<unsigned char> blob;
+    if (overflow) *overflow = false;
     if (n < mirt::kGridMinSpheres || n > 65535u) return blob;
     std::vector<float> radii(n);
     for (uint32_t i = 0; i < n; ++i) radii[i] = std::fabs(sph[i].radius);
@@ -151,7 +153,7 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     }
     size_t n_items = 0;
     for (auto& l : lists) n_items += l.size();
-    if (n_items > 65535u) return blob;                            // cell_start is 16 bit
+    if (n_items > 65535u) { if (overflow) *overflow = true; return blob; }       // cell_start is 16 bit
     mirt::GridHeader h{};
     for (int k = 0; k < 3; ++k) {
         h.org[k] = (float)lo[k];
@@ -191,6 +193,27 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     for (uint32_t i = 0; i < n; ++i) put_rec(h.off_recs + 16 * (size_t)i, (uint16_t)i);
     cells[ncells] = pos;
     return blob;
+}
+
+// The grid mirt_ctx_set_scene keeps: the default cell of 2.5 median radii, coarsened (x 1.26 per step, up to the 4 median radii of
+// round 2 and no further) while the blob would not leave the pooled kernel the 152-slot geometry RTIOW runs (kGridPoolSlotChoices:
+// 160 only fits beside smaller blobs and measured no better) -- or while the cell is so fine that the lists overflow their 16-bit
+// index (bimodal radii: a sphere of 4 median radii spans 5 cells per axis at 2.5, 3 at 4): such a scene built a grid at round 2's
+// cell of 4 and must not lose it to the finer default.  `cell_knob` > 0 (MIRT_GRID_CELL) forces one cell size.
+std::vector<unsigned char> plan_grid(const MirtSphere* sph, uint32_t n, double cell_knob, double big_knob, size_t lds_per_block, double* factor_out)
+{
+    std::vector<unsigned char> grid;
+    double f = cell_knob > 0.0 ? cell_knob : 2.5;
+    for (;; f = std::min(f * 1.26, 4.0)) {
+        bool overflow = false;
+        grid = build_grid(sph, n, f, big_knob, &overflow);
+        if (cell_knob > 0.0 || f >= 4.0) break;                                // a forced cell, or the coarsest one: take what it gives
+        if (grid.empty()) { if (overflow) continue; break; }                   // too many entries: coarser; a grid would not help: none
+        const size_t beside = kx::scene_lds_bytes_grid(n, true) + grid.size();
+        if (beside < lds_per_block && kx::pool_config_grid(lds_per_block - beside).slots >= 152u) break;
+    }
+    if (factor_out) *factor_out = grid.empty() ? 0.0 : f;
+    return grid;
 }
 
 // Tuning / experiment knobs.  They are read from the environment ONCE, when a context is created
@@ -268,9 +291,17 @@ struct MirtContext {
     hipStream_t stream = nullptr;
     // hipEvent pairs around every render kernel, recorded on the stream the kernel runs on;
     // drained (summed) by mirt_ctx_get_stats so that no host sync sits inside a timed loop.
+    // The slots form a RING: a launch takes the next slot and first retires the launch that used it kEventPool launches ago (normally
+    // long finished: one hipEventSynchronize that returns at once) -- no drain of the whole pool, nothing that stalls a caller who queues
+    // launches back to back (the reference's interactive loop: one set_data / render_frame per displayed frame).
     std::vector<hipEvent_t> ev_begin, ev_end;
-    size_t      ev_used = 0;
-    double      ms_folded = 0.0;      // time of pairs already folded because the pool wrapped
+    std::vector<hipEvent_t> ev_zeroed;            // per slot: its dispenser words are zero again (recorded on zero_stream)
+    std::vector<unsigned char> slot_busy;         // a launch is recorded in the slot and not yet folded into ms_folded
+    std::vector<unsigned char> slot_zeroing;      // a re-zeroing of the slot's dispenser words is queued (ev_zeroed says when it is done)
+    size_t      ev_next = 0;          // slot of the next launch
+    size_t      ev_in_flight = 0;     // busy slots: the ring positions ev_next - ev_in_flight .. ev_next - 1
+    hipStream_t zero_stream = nullptr;            // re-zeroes a slot's dispenser words behind the kernel that used them, off the callers' streams
+    double      ms_folded = 0.0;      // time of the launches already retired
     uint64_t    launches_folded = 0;
     double      last_ms = 0.0;
 
@@ -438,6 +469,25 @@ uint32_t mirt_params_out_row_index(const MirtParams* p, uint32_t i)
     return rb + t * p->tile_rows + i % p->tile_rows;
 }
 
+int mirt_grid_plan(const MirtSphere* spheres, uint32_t n_spheres, uint64_t lds_bytes_per_block, MirtGridPlan* out)
+{
+    if (!out || (n_spheres && !spheres)) return fail(MIRT_ERR_NULL_POINTER, "spheres/out is null");
+    *out = MirtGridPlan{};
+    const size_t lds = lds_bytes_per_block ? (size_t)lds_bytes_per_block : (size_t)160 * 1024;
+    double f = 0.0;
+    const std::vector<unsigned char> grid = plan_grid(spheres, n_spheres, 0.0, 0.0, lds, &f);
+    if (grid.empty() || n_spheres > 4095u || kx::scene_lds_bytes_grid(n_spheres, true) + grid.size() > mirt::kMaxLdsBytes) return MIRT_OK;
+    const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
+    out->cell_factor = (float)f;
+    out->blob_bytes = (uint32_t)grid.size();
+    out->n_cells = gh->dims[0] * gh->dims[1] * gh->dims[2];
+    out->n_entries = reinterpret_cast<const uint32_t*>(grid.data() + gh->off_cells)[out->n_cells];
+    out->n_big = gh->n_big;
+    const size_t beside = kx::scene_lds_bytes_grid(n_spheres, true) + grid.size();
+    out->pool_slots = beside < lds ? kx::pool_config_grid(lds - beside).slots : 0u;
+    return MIRT_OK;
+}
+
 int mirt_ctx_create(int device, MirtContext** out)
 {
     if (!out) return fail(MIRT_ERR_NULL_POINTER, "out is null");
@@ -459,12 +509,18 @@ int mirt_ctx_create(int device, MirtContext** out)
         if (e == hipSuccess) e = hipEventCreate(&b);
         if (a) c->ev_begin.push_back(a);
         if (b) c->ev_end.push_back(b);
+        hipEvent_t z = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&z, hipEventDisableTiming);
+        if (z) c->ev_zeroed.push_back(z);
     }
+    c->slot_busy.assign(kEventPool, 0);
+    c->slot_zeroing.assign(kEventPool, 0);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->zero_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters * kEventPool);
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool * kDispenserWords);
-    if (e == hipSuccess) e = hipMemset(c->d_work_counter, 0, sizeof(uint32_t) * kEventPool * kDispenserWords);     // see fold_events
+    if (e == hipSuccess) e = hipMemset(c->d_work_counter, 0, sizeof(uint32_t) * kEventPool * kDispenserWords);     // see retire_slot / launch_render
     if (e != hipSuccess) {
         const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         mirt_ctx_destroy(c);
@@ -483,10 +539,13 @@ void mirt_ctx_destroy(MirtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->zero_stream) (void)hipStreamSynchronize(c->zero_stream);
     (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_shade); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_end) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->ev_zeroed) (void)hipEventDestroy(ev);
+    if (c->zero_stream) (void)hipStreamDestroy(c->zero_stream);
     if (c->ev_accum) (void)hipEventDestroy(c->ev_accum);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -503,15 +562,9 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     const bool fits_flat = kx::scene_lds_bytes(s->n_spheres, s->n_materials, true, true) <= mirt::kMaxLdsBytes;
     // The cell size trades sphere tests against cells walked AND against LDS: the blob shares the CU's 160 KB with the path pools,
     // and a pool geometry lost to a large cell table costs more than finer cells bring (RTIOW: cell = 2 median radii drops the
-    // pools from 152 to 128 slots per wave and the frame from 13.2 to 19.7 ms).  So: the default cell, and coarser ones (x 1.26 per
-    // step, up to the 4 median radii of round 2) only while the blob would not leave the pooled kernel its 152-slot geometry.
-    std::vector<unsigned char> grid;
-    for (double f = c->tuning.grid_cell > 0.0 ? c->tuning.grid_cell : 2.5;; f *= 1.26) {
-        grid = build_grid(s->spheres, s->n_spheres, f, c->tuning.grid_big);
-        if (grid.empty() || c->tuning.grid_cell > 0.0 || f >= 4.0) break;
-        const size_t beside = kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size();
-        if (beside < c->lds_per_block && kx::pool_config_grid(c->lds_per_block - beside).slots >= 152u) break;
-    }
+    // pools from 152 to 128 slots per wave and the frame from 13.2 to 19.7 ms): plan_grid.
+    double grid_factor = 0.0;
+    std::vector<unsigned char> grid = plan_grid(s->spheres, s->n_spheres, c->tuning.grid_cell, c->tuning.grid_big, c->lds_per_block, &grid_factor);
     const bool fits_grid = !grid.empty() && s->n_spheres <= 4095u &&
                            kx::scene_lds_bytes_grid(s->n_spheres, true) + grid.size() <= mirt::kMaxLdsBytes;   // camera (+ sky) + the blob
     if (!fits_flat && !fits_grid)
@@ -681,36 +734,62 @@ static int check_params(const MirtContext* c, const MirtParams* p)
     return MIRT_OK;
 }
 
-// Sum the elapsed time of every recorded event pair into ms_folded and free the pool.
-static int fold_events(MirtContext* c)
+// Retire the launch recorded in slot i (if any): wait for ITS end event -- and for the re-zeroing of its dispenser words, if one was
+// queued -- and add its kernel time to ms_folded.  The slot is then free and its dispenser words are zero.
+static int retire_slot(MirtContext* c, size_t i)
 {
-    for (size_t i = 0; i < c->ev_used; ++i) {
+    if (c->slot_busy[i]) {
         HIP_TRY(hipEventSynchronize(c->ev_end[i]));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
         c->ms_folded += ms;
         c->launches_folded += 1;
         c->last_ms = ms;
+        c->slot_busy[i] = 0;
+        c->ev_in_flight -= 1;
     }
-    // Every launch owns the dispenser words of its event slot, and they start at zero: re-zero the used slots HERE, once per fold
-    // (all their kernels have finished: the events above), instead of one to eight memset nodes in front of every kernel -- 3 us
-    // each, in a stream where a 2-spp frame is 16 us and config 2's 0.9 ms.  Synchronous, so that launches on ANY stream come after it.
-    if (c->ev_used > 0) {
-        HIP_TRY(hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t) * kDispenserWords * c->ev_used, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->slot_zeroing[i]) {
+        HIP_TRY(hipEventSynchronize(c->ev_zeroed[i]));
+        c->slot_zeroing[i] = 0;
     }
-    c->ev_used = 0;
     return MIRT_OK;
+}
+
+// The blocking path (mirt_ctx_get_stats): retire every launch in flight, oldest first (last_ms = the newest launch's time).
+static int fold_events(MirtContext* c)
+{
+    const size_t n = c->ev_begin.size();
+    for (size_t k = c->ev_in_flight; k > 0; --k) {
+        const int rc = retire_slot(c, (c->ev_next + n - k) % n);
+        if (rc != MIRT_OK) return rc;
+    }
+    for (size_t i = 0; i < n; ++i) {                      // (slots whose launch was retired by a later launch but whose zeroing is still queued)
+        const int rc = retire_slot(c, i);
+        if (rc != MIRT_OK) return rc;
+    }
+    return MIRT_OK;
+}
+
+// A launch went wrong after its kernel was enqueued: make the slot safe to reuse whatever state the stream is in.
+static void poison_slot(MirtContext* c, size_t i, hipStream_t stream)
+{
+    (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(c->zero_stream);
+    (void)hipMemset(c->d_work_counter + i * kDispenserWords, 0, sizeof(uint32_t) * kDispenserWords);
+    if (c->slot_busy[i]) { c->slot_busy[i] = 0; c->ev_in_flight -= 1; }
+    c->slot_zeroing[i] = 0;
 }
 
 static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream,
                          unsigned long long* d_accum = nullptr)
 {
-    if (c->ev_used == c->ev_begin.size()) {      // pool exhausted: fold (one sync per 64 launches)
-        const int rc = fold_events(c);
+    // the ring's next slot; the launch that used it kEventPool launches ago is retired first (its end event has normally completed long
+    // ago, and so has the re-zeroing of its dispenser words: both waits return at once -- the pipeline is never drained)
+    const size_t ev = c->ev_next;
+    {
+        const int rc = retire_slot(c, ev);
         if (rc != MIRT_OK) return rc;
     }
-    const size_t ev = c->ev_used;
     const uint32_t rows = out_rows(p);
     const uint64_t npix = (uint64_t)rows * p->width;
     const bool count = (p->flags & MIRT_FLAG_COUNT_WORK) != 0;
@@ -899,7 +978,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // The pooled kernel's strips last long at high sample counts (config 3: 9 atomics per microsecond); below 128 spp they do not
     // (three spheres, 1080p, pool forced: 48 / 64 / 100 / 200 spp -13.5 / -8.5 / -2 / +1 % with eight words; RTIOW 16 spp -4.5 %).
     a.spread_units = (a.static_units == 0u && tune.spread_units != 0 && (!pool || p->spp < 128u)) ? 1u : 0u;
-    a.first_dispensed = launched_waves;          // the words themselves are zero (fold_events): no memset node in front of the kernel
+    a.first_dispensed = launched_waves;          // the words themselves are zero (retire_slot): no memset node in front of the kernel
     for (uint32_t x = 0; x < 8u; ++x) a.disp_taken[x] = launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u;
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
@@ -922,12 +1001,30 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
                  tf[use_grid], tf[by_pixel]);
     }
-    HIP_TRY(hipEventRecord(c->ev_end[ev], stream));
-    if (d_accum) {                                   // resolve/read must see these sums whatever stream they were added on
-        HIP_TRY(hipEventRecord(c->ev_accum, stream));
-        c->accum_pending = true;
+    // The kernel is enqueued: from here on the slot is in use, whatever happens below (a failure after this point must not hand the
+    // slot -- its dispenser words no longer zero -- to the next launch: poison_slot).
+    c->slot_busy[ev] = 1;
+    c->ev_in_flight += 1;
+    c->ev_next = (ev + 1) % c->ev_begin.size();
+    hipError_t he = hipEventRecord(c->ev_end[ev], stream);
+    // Kernels that take units from the dispenser leave its words non-zero.  They are re-zeroed behind THIS kernel's end event on the
+    // context's own zero_stream -- one 8-row 2D memset over the eight words (4 KB apart) --, not on the caller's stream, where a memset
+    // node costs 3 us between kernels; the slot's next user, kEventPool launches later, waits for ev_zeroed (retire_slot).  Launches whose
+    // units are dealt round-robin (the reference's 2-spp frames, parity mode's lane = pixel) never touch the words: nothing to do.
+    if (he == hipSuccess && a.static_units == 0u) {
+        he = hipStreamWaitEvent(c->zero_stream, c->ev_end[ev], 0);
+        if (he == hipSuccess) he = hipMemset2DAsync(a.work_counter, sizeof(uint32_t) * kDispenserStride, 0, sizeof(uint32_t), 8, c->zero_stream);
+        if (he == hipSuccess) he = hipEventRecord(c->ev_zeroed[ev], c->zero_stream);
+        if (he == hipSuccess) c->slot_zeroing[ev] = 1;
     }
-    c->ev_used = ev + 1;
+    if (he == hipSuccess && d_accum) {               // resolve/read must see these sums whatever stream they were added on
+        he = hipEventRecord(c->ev_accum, stream);
+        if (he == hipSuccess) c->accum_pending = true;
+    }
+    if (he != hipSuccess) {
+        poison_slot(c, ev, stream);
+        return fail(MIRT_ERR_HIP, "%s", hipGetErrorString(he));
+    }
     c->last_slot = ev;
     c->stats_counted = count;
     c->stats = MirtStats{};
@@ -968,7 +1065,8 @@ int mirt_ctx_synchronize(MirtContext* c)
 {
     if (!c) return fail(MIRT_ERR_NULL_POINTER, "ctx is null");
     HIP_TRY(hipSetDevice(c->device));
-    for (size_t i = 0; i < c->ev_used; ++i) HIP_TRY(hipEventSynchronize(c->ev_end[i]));
+    for (size_t i = 0; i < c->ev_begin.size(); ++i) if (c->slot_busy[i]) HIP_TRY(hipEventSynchronize(c->ev_end[i]));
+    HIP_TRY(hipStreamSynchronize(c->zero_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MIRT_OK;
 }
@@ -977,7 +1075,7 @@ int mirt_ctx_get_stats(MirtContext* c, MirtStats* out)
 {
     if (!c || !out) return fail(MIRT_ERR_NULL_POINTER, "ctx/out is null");
     HIP_TRY(hipSetDevice(c->device));
-    const bool had_launch = c->ev_used > 0;
+    const bool had_launch = c->ev_in_flight > 0 || c->launches_folded > 0;
     const int rc = fold_events(c);
     if (rc != MIRT_OK) return rc;
     c->stats.kernel_ms = c->last_ms;

@@ -510,14 +510,16 @@ class Raytracer:
         return SceneData(self.camera.c, [s.to_c() for s in self.spheres], list(self.material_data),
                          self.global_texture_data, self.sky_state)
 
-    def _params(self, spp: int, seed: int, flags: int) -> _abi.MirtParams:
+    def _params(self, spp: int, seed: int, flags: int, frame_begin: Optional[int] = None) -> _abi.MirtParams:
         rp = self.render_params
         if self.sky_state is not None:
             flags |= _abi.MIRT_FLAG_SKY_HOSEK
+        if frame_begin is None:
+            frame_begin = self._frame_begin
         return make_params(rp.viewport_size[0], rp.viewport_size[1], spp, mode=_abi.MIRT_MODE_PT,
                            num_bounces=rp.sampling.num_bounces, flags=flags, seed=seed,
                            frame_spp=rp.sampling.num_samples_per_pixel if self.reference_stream else 0,
-                           frame_begin=self._frame_begin if self.reference_stream else 0)
+                           frame_begin=frame_begin if self.reference_stream else 0)
 
     def render_frame(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
         """`Raytracer::render_frame` (mod.rs:303-351) without the wgpu draw: add
@@ -544,9 +546,15 @@ class Raytracer:
         self._ctx.set_camera(self.camera.c)
         self._accumulated = None                               # render_progress.reset() mod.rs:385
 
-    def render(self, *, seed: int = 0, flags: int = 0) -> np.ndarray:
-        """All `max_samples_per_pixel` samples in one launch -> RGBA8 [h][w][4]."""
-        params = self._params(self.render_params.sampling.max_samples_per_pixel, seed, flags)
+    def render(self, *, seed: int = 0, flags: int = 0, frame_begin: int = 0) -> np.ndarray:
+        """All `max_samples_per_pixel` samples in one launch -> RGBA8 [h][w][4].
+
+        With `reference_stream=True` the launch is the accumulation a FRESH reference `Raytracer` would converge to: its frames are
+        numbered frame_begin + 1, frame_begin + 2, ... with `frame_begin = 0` by default -- not the frame count of this object's
+        progressive loop, so the image does not depend on earlier `render_frame` / `set_render_params` calls.  Pass
+        `frame_begin=rt.frame_number - 1` for the accumulation the progressive loop would start NOW.  Ignored without
+        `reference_stream` (one stream per sample)."""
+        params = self._params(self.render_params.sampling.max_samples_per_pixel, seed, flags, frame_begin=frame_begin)
         img = self._ctx.render(params)
         self.last_stats = self._ctx.stats()
         return img
