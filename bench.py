@@ -202,10 +202,28 @@ def base_params(m, cfg: dict, flags: int = 0):
 
 
 def host_cores() -> int:
+    """CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota where one is set (a GPU box hands a
+    one-GPU job a share of a 256-thread host: 256 OpenMP threads on a 16-CPU quota measure the scheduler, not the code)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                    # cgroup v2
+        q, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def cpu_baseline(m, sd, cfg: dict, target_seconds: float = 12.0, repeats: int = 3) -> dict:

@@ -119,7 +119,7 @@ def test_grid_plan_of_the_rtiow_scene():
     scene, _ = m.scenes.rtiow_final()
     g = _grid_plan([s.to_c() for s in scene.spheres])
     assert g.cell_factor == 2.5 and g.n_big == 4 and g.pool_slots == 152            # ground + the three r = 1 spheres stay outside the grid
-    assert 0 < g.blob_bytes < 24 * 1024 and g.n_cells <= 8192 and 0 < g.n_entries < 65536
+    assert 0 < g.blob_bytes < 26 * 1024 and g.n_cells <= 8192 and 0 < g.n_entries < 65536         # 24 640 B: two u32 per cell since round 4
     assert _grid_plan([s.to_c() for s in scene.spheres[:20]]).cell_factor == 0.0      # fewer than 32 spheres: no grid
 
 
@@ -136,3 +136,14 @@ def test_grid_plan_coarsens_past_an_entry_overflow():
     rng = np.random.default_rng(5)
     uni = [m.Sphere.new(tuple(float(x) for x in rng.uniform(-3, 3, 3)), 0.05, 0).to_c() for _ in range(3000)]
     assert 2.5 <= _grid_plan(uni).cell_factor <= 4.0
+
+
+def test_parked_cell_indices_come_apart_exactly():
+    """A cut grid walk parks its LINEAR cell index (16 bit); the kernel takes it apart with float reciprocals computed on the host
+    (GridHeader.inv_dim_x / inv_dim_xy): floor((n + 0.5) * fl(1 / d)) == n // d for every n, d <= 8192 (kGridMaxCells)."""
+    import numpy as np
+    n = np.arange(8192, dtype=np.float32) + np.float32(0.5)
+    whole = np.arange(8192) 
+    for d in range(1, 8193):
+        q = (n * (np.float32(1.0) / np.float32(d))).astype(np.uint32)
+        assert np.array_equal(q, (whole // d).astype(np.uint32)), d

@@ -283,6 +283,7 @@ def test_launches_of_one_context_overlap_on_two_streams(gpu_ctx, oracle):
     for rep in range(3):
         a = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         b = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.current_stream().synchronize()         # the fills run on torch's current stream, the renders on s1 / s2: order them
         gpu_ctx.render_device(pa, a.data_ptr(), a.numel(), s1.cuda_stream)
         gpu_ctx.render_device(pb, b.data_ptr(), b.numel(), s2.cuda_stream)
         outs.append((a, b))

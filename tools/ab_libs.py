@@ -42,7 +42,7 @@ libs = []
 for spec in a.libs:
     path, _, envs = spec.partition("@")
     lib = C.CDLL(str(Path(path).resolve()))
-    _abi.bind(lib)
+    _abi.bind(lib, {k: v for k, v in _abi.SYMBOLS.items() if hasattr(lib, k)})       # a build older than the header has fewer exports
     ctx = C.c_void_p()
     knobs = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
     saved = {k: os.environ.get(k) for k in knobs}

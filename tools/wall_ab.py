@@ -2,7 +2,11 @@
 """Like ab_libs.py, but WALL time of N launches queued back to back on one stream (mirt_ctx_render_device into device memory, one
 synchronize at the end) -- what consecutive bench steps or interactive frames cost, launch gaps and dispenser set-up included.
 
-    python tools/wall_ab.py [--scene S] [--size WxH] [--spp N] [--launches 50] [--rounds 7] lib_a.so lib_b.so ...
+    python tools/wall_ab.py [--scene S] [--mode pt|parity] [--size WxH] [--spp N] [--launches 50] [--rounds 7] lib_a.so lib_b.so ...
+
+`--scene layer_scene --mode parity --size 800x600 --spp 2 --launches 200` is the reference's own loop (`Layer::set_data` at its operating
+point); more than 64 launches per round cross the context's ring of launch slots.  A build older than the header (fewer exports) is bound
+with the symbols it has.
 """
 import argparse
 import ctypes as C
@@ -17,25 +21,26 @@ sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 import torch  # noqa: E402
 import weekend_raytracer_wgpu_amd as m  # noqa: E402
 from weekend_raytracer_wgpu_amd import _abi  # noqa: E402
-from helpers import scene_data  # noqa: E402
+from helpers import layer_scene_data, scene_data  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="three_spheres")
 ap.add_argument("--size", default="1920x1080")
+ap.add_argument("--mode", default="pt")
 ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--launches", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 w, h = map(int, a.size.split("x"))
-sd = scene_data(a.scene, w, h)
-p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT, num_bounces=8)
+sd = layer_scene_data(w, h) if a.scene == "layer_scene" else scene_data(a.scene, w, h)
+p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT if a.mode == "pt" else m.MIRT_MODE_PARITY, num_bounces=8)
 out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.Stream()
 libs = []
 for path in a.libs:
     lib = C.CDLL(str(Path(path).resolve()))
-    _abi.bind(lib)
+    _abi.bind(lib, {k: v for k, v in _abi.SYMBOLS.items() if hasattr(lib, k)})
     ctx = C.c_void_p()
     assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
     sc = sd.as_c()

@@ -151,9 +151,12 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
             for (int y = c0[1]; y <= c1[1]; ++y)
                 for (int x = c0[0]; x <= c1[0]; ++x) lists[((size_t)z * dims[1] + y) * dims[0] + x].push_back(i);   // ascending ids
     }
-    size_t n_items = 0;
-    for (auto& l : lists) n_items += l.size();
-    if (n_items > 65535u) { if (overflow) *overflow = true; return blob; }       // cell_start is 16 bit
+    size_t n_items = 0, n_entries = 0;
+    for (auto& l : lists) {
+        n_entries += l.size();
+        n_items += l.size() > 2 ? l.size() - 2 : 0;             // the first two ids of a cell live in its table entry
+    }
+    if (n_entries > 65535u) { if (overflow) *overflow = true; return blob; }     // cell_start is 16 bit
     mirt::GridHeader h{};
     for (int k = 0; k < 3; ++k) {
         h.org[k] = (float)lo[k];
@@ -167,9 +170,12 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     h.off_items = h.off_big + (uint32_t)big.size();
     size_t bytes = ((size_t)h.off_items + n_items) * 2;
     h.off_ops = (uint32_t)bytes;                                  // u8 per sphere, filled by the caller (needs the materials)
-    bytes = (bytes + n + 3) & ~size_t(3);
-    h.off_cells = (uint32_t)bytes;                                // u32 per cell: first item | count << 16
-    bytes = (bytes + 4 * ((size_t)ncells + 1) + 15) & ~size_t(15);     // + one entry: `first` of the end of the list
+    bytes = (bytes + n + 7) & ~size_t(7);
+    h.off_cells = (uint32_t)bytes;                                // two u32 per cell: first further item | count << 16, id0 | id1 << 16
+    bytes = (bytes + 8 * (size_t)ncells + 15) & ~size_t(15);
+    h.n_entries = (uint32_t)n_entries;
+    h.inv_dim_x = 1.0f / (float)dims[0];
+    h.inv_dim_xy = 1.0f / (float)(dims[0] * dims[1]);
     h.off_big_recs = (uint32_t)bytes;
     bytes += big.size() * 16;
     h.off_recs = (uint32_t)bytes;
@@ -187,11 +193,12 @@ std::vector<unsigned char> build_grid(const MirtSphere* sph, uint32_t n, double 
     for (size_t i = 0; i < big.size(); ++i) { u[h.off_big + i] = big[i]; put_rec(h.off_big_recs + 16 * i, big[i]); }
     uint32_t pos = 0;
     for (uint32_t c = 0; c < ncells; ++c) {
-        cells[c] = pos | ((uint32_t)lists[c].size() << 16);       // n_items <= 65535, so both halves fit
-        for (uint16_t id : lists[c]) u[h.off_items + pos++] = id;
+        const auto& l = lists[c];
+        cells[2 * c] = pos | ((uint32_t)l.size() << 16);
+        cells[2 * c + 1] = (l.size() > 0 ? (uint32_t)l[0] : 0u) | ((l.size() > 1 ? (uint32_t)l[1] : 0u) << 16);   // absent: sphere 0 (valid, never tested)
+        for (size_t k = 2; k < l.size(); ++k) u[h.off_items + pos++] = l[k];
     }
     for (uint32_t i = 0; i < n; ++i) put_rec(h.off_recs + 16 * (size_t)i, (uint16_t)i);
-    cells[ncells] = pos;
     return blob;
 }
 
@@ -234,6 +241,7 @@ struct Tuning {
     int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed / dealt round-robin (A/B runs)
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
+    bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
 };
 
 Tuning read_tuning()
@@ -252,6 +260,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_STATIC_UNITS")) t.static_units = (e[0] == '1') ? 1 : 0;
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
 }
@@ -291,16 +300,18 @@ struct MirtContext {
     hipStream_t stream = nullptr;
     // hipEvent pairs around every render kernel, recorded on the stream the kernel runs on;
     // drained (summed) by mirt_ctx_get_stats so that no host sync sits inside a timed loop.
-    // The slots form a RING: a launch takes the next slot and first retires the launch that used it kEventPool launches ago (normally
-    // long finished: one hipEventSynchronize that returns at once) -- no drain of the whole pool, nothing that stalls a caller who queues
-    // launches back to back (the reference's interactive loop: one set_data / render_frame per displayed frame).
+    // The slots form a RING: a launch takes the next slot; the slots half a ring ahead are retired in batches of 16 (launches 17 to 32
+    // launches old, normally long finished: waits that return at once) -- no drain of the whole pool, nothing that stalls a caller who
+    // queues launches back to back (the reference's interactive loop: one set_data / render_frame per displayed frame).
     std::vector<hipEvent_t> ev_begin, ev_end;
     std::vector<hipEvent_t> ev_zeroed;            // per slot: its dispenser words are zero again (recorded on zero_stream)
     std::vector<unsigned char> slot_busy;         // a launch is recorded in the slot and not yet folded into ms_folded
+    std::vector<unsigned char> slot_dirty;        // the slot's launch took units from its dispenser words: they must be re-zeroed before the next use
     std::vector<unsigned char> slot_zeroing;      // a re-zeroing of the slot's dispenser words is queued (ev_zeroed says when it is done)
+    std::vector<unsigned char> slot_zero_event;   // ... and which ev_zeroed: the slot's own, or its batch's first slot (retire_slots)
     size_t      ev_next = 0;          // slot of the next launch
     size_t      ev_in_flight = 0;     // busy slots: the ring positions ev_next - ev_in_flight .. ev_next - 1
-    hipStream_t zero_stream = nullptr;            // re-zeroes a slot's dispenser words behind the kernel that used them, off the callers' streams
+    hipStream_t zero_stream = nullptr;            // re-zeroes the dispenser words of retired slots, off the callers' streams
     double      ms_folded = 0.0;      // time of the launches already retired
     uint64_t    launches_folded = 0;
     double      last_ms = 0.0;
@@ -475,13 +486,14 @@ int mirt_grid_plan(const MirtSphere* spheres, uint32_t n_spheres, uint64_t lds_b
     *out = MirtGridPlan{};
     const size_t lds = lds_bytes_per_block ? (size_t)lds_bytes_per_block : (size_t)160 * 1024;
     double f = 0.0;
-    const std::vector<unsigned char> grid = plan_grid(spheres, n_spheres, 0.0, 0.0, lds, &f);
+    const Tuning tune = read_tuning();                 // the experiment knobs MIRT_GRID_CELL / MIRT_GRID_BIG apply as in mirt_ctx_create
+    const std::vector<unsigned char> grid = plan_grid(spheres, n_spheres, tune.grid_cell, tune.grid_big, lds, &f);
     if (grid.empty() || n_spheres > 4095u || kx::scene_lds_bytes_grid(n_spheres, true) + grid.size() > mirt::kMaxLdsBytes) return MIRT_OK;
     const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
     out->cell_factor = (float)f;
     out->blob_bytes = (uint32_t)grid.size();
     out->n_cells = gh->dims[0] * gh->dims[1] * gh->dims[2];
-    out->n_entries = reinterpret_cast<const uint32_t*>(grid.data() + gh->off_cells)[out->n_cells];
+    out->n_entries = gh->n_entries;
     out->n_big = gh->n_big;
     const size_t beside = kx::scene_lds_bytes_grid(n_spheres, true) + grid.size();
     out->pool_slots = beside < lds ? kx::pool_config_grid(lds - beside).slots : 0u;
@@ -515,12 +527,14 @@ int mirt_ctx_create(int device, MirtContext** out)
     }
     c->slot_busy.assign(kEventPool, 0);
     c->slot_zeroing.assign(kEventPool, 0);
+    c->slot_dirty.assign(kEventPool, 0);
+    c->slot_zero_event.assign(kEventPool, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->zero_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, sizeof(unsigned long long) * mirt::kNumCounters * kEventPool);
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, sizeof(uint32_t) * kEventPool * kDispenserWords);
-    if (e == hipSuccess) e = hipMemset(c->d_work_counter, 0, sizeof(uint32_t) * kEventPool * kDispenserWords);     // see retire_slot / launch_render
+    if (e == hipSuccess) e = hipMemset(c->d_work_counter, 0, sizeof(uint32_t) * kEventPool * kDispenserWords);     // see retire_slots / launch_render
     if (e != hipSuccess) {
         const int rc = fail(MIRT_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         mirt_ctx_destroy(c);
@@ -645,7 +659,10 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     }
     if (!grid.empty()) {                         // routine queue of every sphere, for the grid builds (GridHeader.off_ops)
         const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
-        for (uint32_t i = 0; i < s->n_spheres; ++i) grid[gh->off_ops + i] = (unsigned char)prep[i].op;
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {            // the ROUTINE itself, min(GpuMaterial.id, 4): what the scatter step switches on
+            const uint32_t mi = s->spheres[i].material_idx;
+            grid[gh->off_ops + i] = (unsigned char)((mi < s->n_materials && s->materials[mi].id < 4u) ? s->materials[mi].id : 4u);
+        }
     }
     // grid builds: sphere centre, 1/r and a copy of the sphere's material in one 64-byte record (mirt_kernels.h: ShadeRec)
     std::vector<mirt::ShadeRec> shade;
@@ -653,7 +670,12 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         shade.resize(s->n_spheres);
         for (uint32_t i = 0; i < s->n_spheres; ++i) {
             const uint32_t mi = prep[i].material_idx < s->n_materials ? prep[i].material_idx : 0u;   // out of range: pt_scene_status refuses the launch
-            shade[i] = mirt::ShadeRec{ prep[i].cx, prep[i].cy, prep[i].cz, prep[i].inv_r, pmats[mi] };
+            const mirt::PreparedMaterial& pm = pmats[mi];
+            float fl, idf;
+            std::memcpy(&fl, &pm.flags, 4);
+            std::memcpy(&idf, &pm.id, 4);
+            shade[i] = mirt::ShadeRec{ { prep[i].inv_r, pm.x, pm.inv_x, fl }, { pm.tex[0][0], pm.tex[0][1], pm.tex[0][2], pm.tex[0][3] },
+                                       { pm.tex[1][0], pm.tex[1][1], pm.tex[1][2], pm.tex[1][3] }, { prep[i].cx, prep[i].cy, prep[i].cz, idf } };
         }
     }
     int rc;
@@ -675,7 +697,7 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
         c->grid_packable = false;
         if (fits_grid) {
             const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
-            c->grid_packable = gh->dims[0] <= 1024u && gh->dims[1] <= 1024u && gh->dims[2] <= 1024u;
+            c->grid_packable = gh->dims[0] * gh->dims[1] * gh->dims[2] <= mirt::kGridMaxCells;      // a parked walk keeps its linear cell index (16 bit)
         }
         if (fits_grid) {
             if ((rc = ensure_capacity(&c->d_grid, &c->cap_grid, grid.size())) != MIRT_OK) return rc;
@@ -734,37 +756,74 @@ static int check_params(const MirtContext* c, const MirtParams* p)
     return MIRT_OK;
 }
 
-// Retire the launch recorded in slot i (if any): wait for ITS end event -- and for the re-zeroing of its dispenser words, if one was
-// queued -- and add its kernel time to ms_folded.  The slot is then free and its dispenser words are zero.
-static int retire_slot(MirtContext* c, size_t i)
+// ---- the ring of launch slots ----
+// Wait for the launch recorded in slot i (if any) and add its kernel time to ms_folded.
+static int fold_slot(MirtContext* c, size_t i)
 {
-    if (c->slot_busy[i]) {
-        HIP_TRY(hipEventSynchronize(c->ev_end[i]));
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
-        c->ms_folded += ms;
-        c->launches_folded += 1;
-        c->last_ms = ms;
-        c->slot_busy[i] = 0;
-        c->ev_in_flight -= 1;
+    if (!c->slot_busy[i]) return MIRT_OK;
+    HIP_TRY(hipEventSynchronize(c->ev_end[i]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+    c->ms_folded += ms;
+    c->launches_folded += 1;
+    c->last_ms = ms;
+    c->slot_busy[i] = 0;
+    c->ev_in_flight -= 1;
+    return MIRT_OK;
+}
+
+// Wait until a re-zeroing queued for slot i has landed.
+static int await_zero(MirtContext* c, size_t i)
+{
+    if (!c->slot_zeroing[i]) return MIRT_OK;
+    HIP_TRY(hipEventSynchronize(c->ev_zeroed[c->slot_zero_event[i]]));
+    c->slot_zeroing[i] = 0;
+    return MIRT_OK;
+}
+
+// Retire slots [first, first + n): fold their launches' times and -- if any of their kernels took units from the dispenser
+// (slot_dirty) -- re-zero the dispenser words of all of them with ONE memset on the context's zero_stream (the eight words of a slot
+// sit 4 KB apart: 32 KB per slot).  The host has seen every kernel's end before it queues the memset, so no stream ever waits on
+// another stream's event; ev_zeroed[first] says when the memset has landed (await_zero).
+static int retire_slots(MirtContext* c, size_t first, size_t n)
+{
+    bool dirty = false;
+    for (size_t i = first; i < first + n; ++i) {
+        int rc = await_zero(c, i);                                  // (an earlier memset of this slot: let it land first)
+        if (rc == MIRT_OK) rc = fold_slot(c, i);
+        if (rc != MIRT_OK) return rc;
+        dirty = dirty || c->slot_dirty[i];
     }
-    if (c->slot_zeroing[i]) {
-        HIP_TRY(hipEventSynchronize(c->ev_zeroed[i]));
-        c->slot_zeroing[i] = 0;
+    if (!dirty) return MIRT_OK;
+    HIP_TRY(hipMemsetAsync(c->d_work_counter + first * kDispenserWords, 0, sizeof(uint32_t) * kDispenserWords * n, c->zero_stream));
+    HIP_TRY(hipEventRecord(c->ev_zeroed[first], c->zero_stream));
+    for (size_t i = first; i < first + n; ++i) {
+        c->slot_dirty[i] = 0;
+        c->slot_zeroing[i] = 1;
+        c->slot_zero_event[i] = (unsigned char)first;
     }
     return MIRT_OK;
 }
 
-// The blocking path (mirt_ctx_get_stats): retire every launch in flight, oldest first (last_ms = the newest launch's time).
+// The ring retires its slots in batches of 16, half a ring ahead of the slot in use (launch_render): one small fill kernel per 16
+// launches instead of one per launch (per-launch fills cost the dispensed 4-spp frame 2.4 %, profiles/r04_ring_ab.txt).
+constexpr size_t kRingBatch = 16;
+
+// The blocking path (mirt_ctx_get_stats): fold every launch in flight, oldest first (last_ms = the newest launch's time), and leave
+// every slot clean.
 static int fold_events(MirtContext* c)
 {
     const size_t n = c->ev_begin.size();
     for (size_t k = c->ev_in_flight; k > 0; --k) {
-        const int rc = retire_slot(c, (c->ev_next + n - k) % n);
+        const int rc = fold_slot(c, (c->ev_next + n - k) % n);
         if (rc != MIRT_OK) return rc;
     }
-    for (size_t i = 0; i < n; ++i) {                      // (slots whose launch was retired by a later launch but whose zeroing is still queued)
-        const int rc = retire_slot(c, i);
+    for (size_t b = 0; b < n / kRingBatch; ++b) {
+        const int rc = retire_slots(c, b * kRingBatch, kRingBatch);
+        if (rc != MIRT_OK) return rc;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const int rc = await_zero(c, i);
         if (rc != MIRT_OK) return rc;
     }
     return MIRT_OK;
@@ -778,17 +837,30 @@ static void poison_slot(MirtContext* c, size_t i, hipStream_t stream)
     (void)hipMemset(c->d_work_counter + i * kDispenserWords, 0, sizeof(uint32_t) * kDispenserWords);
     if (c->slot_busy[i]) { c->slot_busy[i] = 0; c->ev_in_flight -= 1; }
     c->slot_zeroing[i] = 0;
+    c->slot_dirty[i] = 0;
 }
 
 static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, hipStream_t stream,
                          unsigned long long* d_accum = nullptr)
 {
-    // the ring's next slot; the launch that used it kEventPool launches ago is retired first (its end event has normally completed long
-    // ago, and so has the re-zeroing of its dispenser words: both waits return at once -- the pipeline is never drained)
+    // The ring's next slot.  When the ring enters a batch of 16 slots, the batch HALF A RING AHEAD is retired (retire_slots): its launches
+    // -- 32 to 17 launches old -- have normally finished long ago (the waits return at once; a caller more than 17 launches ahead of the
+    // GPU is held here, which is what a bounded queue should do), their times are folded and their dispenser words re-zeroed on the
+    // context's own stream.  By the time the ring reaches those slots they are clean: the pipeline is never drained.
+    static_assert(kEventPool % (2 * kRingBatch) == 0, "the ring is a whole number of batch pairs");
     const size_t ev = c->ev_next;
     {
-        const int rc = retire_slot(c, ev);
+        int rc = MIRT_OK;
+        if (ev % kRingBatch == 0) rc = retire_slots(c, (ev + kEventPool / 2) % kEventPool, kRingBatch);
+        if (rc == MIRT_OK && (c->slot_busy[ev] || c->slot_dirty[ev])) rc = retire_slots(c, ev, 1);   // (not in the normal flow: the batch ahead was retired 32 launches ago)
+        if (rc == MIRT_OK) rc = await_zero(c, ev);               // at most one wait for the batch's memset, 32 launches old
         if (rc != MIRT_OK) return rc;
+        if (c->tuning.debug_slots) {                 // MIRT_DEBUG_SLOTS=1 (tests): the slot's eight dispenser words ARE zero now
+            uint32_t wds[8];
+            HIP_TRY(hipMemcpy2D(wds, sizeof(uint32_t), c->d_work_counter + ev * kDispenserWords, sizeof(uint32_t) * kDispenserStride, sizeof(uint32_t), 8, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 8; ++k)
+                if (wds[k] != 0u) return fail(MIRT_ERR_HIP, "launch slot %zu: dispenser word %d holds %u before the launch", ev, k, wds[k]);
+        }
     }
     const uint32_t rows = out_rows(p);
     const uint64_t npix = (uint64_t)rows * p->width;
@@ -829,7 +901,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // one 1024-thread block per CU; its path pools take what scene + grid leave of the block's LDS (counting launches:
     // the largest geometry only)
     const size_t lds_beside = scene_lds_g + c->grid_bytes;
-    mirt::PoolConfig pcg = kx::pool_config_grid((size_t)c->lds_per_block > lds_beside ? (size_t)c->lds_per_block - lds_beside : 0);
+    const size_t lds_grid_block = (size_t)c->lds_per_block / mirt::kGridPoolBlocksPerCu;
+    mirt::PoolConfig pcg = kx::pool_config_grid(lds_grid_block > lds_beside ? lds_grid_block - lds_beside : 0);
     if (count && pcg.slots != mirt::kGridPoolSlotChoices[0] && pcg.slots != mirt::kGridPoolSlotChoices[1]) pcg.slots = 0;
     const size_t lds_pool_grid_block = lds_beside + pcg.lds_bytes;
     const uint32_t pool_grid_waves_per_cu = pcg.slots ? (uint32_t)(c->lds_per_cu / lds_pool_grid_block) * (pcg.threads / 64u) : 0u;
@@ -978,7 +1051,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // The pooled kernel's strips last long at high sample counts (config 3: 9 atomics per microsecond); below 128 spp they do not
     // (three spheres, 1080p, pool forced: 48 / 64 / 100 / 200 spp -13.5 / -8.5 / -2 / +1 % with eight words; RTIOW 16 spp -4.5 %).
     a.spread_units = (a.static_units == 0u && tune.spread_units != 0 && (!pool || p->spp < 128u)) ? 1u : 0u;
-    a.first_dispensed = launched_waves;          // the words themselves are zero (retire_slot): no memset node in front of the kernel
+    a.first_dispensed = launched_waves;          // the words themselves are zero (retire_slots): no memset node in front of the kernel
     for (uint32_t x = 0; x < 8u; ++x) a.disp_taken[x] = launched_waves > x ? (launched_waves - x + 7u) / 8u : 0u;
 #ifdef MIRT_DIAG_STAMPS
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
@@ -1007,16 +1080,10 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     c->ev_in_flight += 1;
     c->ev_next = (ev + 1) % c->ev_begin.size();
     hipError_t he = hipEventRecord(c->ev_end[ev], stream);
-    // Kernels that take units from the dispenser leave its words non-zero.  They are re-zeroed behind THIS kernel's end event on the
-    // context's own zero_stream -- one 8-row 2D memset over the eight words (4 KB apart) --, not on the caller's stream, where a memset
-    // node costs 3 us between kernels; the slot's next user, kEventPool launches later, waits for ev_zeroed (retire_slot).  Launches whose
-    // units are dealt round-robin (the reference's 2-spp frames, parity mode's lane = pixel) never touch the words: nothing to do.
-    if (he == hipSuccess && a.static_units == 0u) {
-        he = hipStreamWaitEvent(c->zero_stream, c->ev_end[ev], 0);
-        if (he == hipSuccess) he = hipMemset2DAsync(a.work_counter, sizeof(uint32_t) * kDispenserStride, 0, sizeof(uint32_t), 8, c->zero_stream);
-        if (he == hipSuccess) he = hipEventRecord(c->ev_zeroed[ev], c->zero_stream);
-        if (he == hipSuccess) c->slot_zeroing[ev] = 1;
-    }
+    // Kernels that take units from the dispenser leave its words non-zero: retire_slots re-zeroes them before the slot's next use, on the
+    // context's zero_stream -- never a memset node on the caller's stream, where it costs 3 us between kernels.  Launches whose units are
+    // dealt round-robin (the reference's 2-spp frames, parity mode's lane = pixel) never touch the words.
+    if (a.static_units == 0u) c->slot_dirty[ev] = 1;
     if (he == hipSuccess && d_accum) {               // resolve/read must see these sums whatever stream they were added on
         he = hipEventRecord(c->ev_accum, stream);
         if (he == hipSuccess) c->accum_pending = true;

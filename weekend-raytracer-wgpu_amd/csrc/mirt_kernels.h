@@ -36,12 +36,15 @@ struct PreparedMaterial {
 };
 static_assert(sizeof(PreparedMaterial) == 48, "PreparedMaterial is 3 x 16 B");
 
-// Many-sphere scenes (grid builds): what shading a hit on sphere i needs, in ONE 64-byte line of global memory / L2 --
-// the sphere's centre and 1/r and a copy of its material -- so that the scatter step issues four independent 16-byte
-// loads instead of sphere -> material_idx -> material (two dependent round trips of 200+ cycles each at 4 waves per SIMD).
+// Many-sphere scenes (grid builds): what shading a hit on sphere i needs besides what the grid blob already holds in LDS (centre,
+// routine id): 1/r and the sphere's material, in ONE 64-byte line of global memory -- no sphere -> material_idx -> material chain.
+// The scatter step loads `a` and `t0` (two independent 16-byte loads; `t1` only in the checkerboard's case) and uses them after
+// the routine's random draws (mirt_kernels.hip: shade_grid_hit).
 struct ShadeRec {
-    float            cx, cy, cz, inv_r;
-    PreparedMaterial m;
+    float a[4];        // {1/r, x, 1/x, bits(flags)}
+    float t0[4];       // first texture (PreparedMaterial.tex[0])
+    float t1[4];       // second texture (checkerboard only)
+    float c[4];        // {centre, bits(id)}: not read by the kernels (centre and routine id come from the grid blob in LDS)
 };
 static_assert(sizeof(ShadeRec) == 64, "ShadeRec is one 64-byte line");
 
@@ -50,15 +53,16 @@ static_assert(sizeof(ShadeRec) == 64, "ShadeRec is one 64-byte line");
 // CONSERVATIVE (every sphere is listed in all cells its slightly enlarged bounding box touches) and the
 // hit rule breaks ties by sphere index, so the result is identical to the reference's flat scan.
 // Layout of the blob (all of it is staged into LDS; the kernels of a grid build read NO other sphere data from LDS):
-//   GridHeader | big ids [n_big] u16 | item ids [n_items] u16 (ascending within a cell)
-//   | routine queue of every sphere [n_spheres] u8 (PreparedSphere.op)
-//   | 4-byte aligned: cell table [ncells + 1] u32 = first item | item count << 16 (one LDS read per cell)
+//   GridHeader | big ids [n_big] u16 | FURTHER item ids [n_items] u16 (a cell's third, fourth ... sphere, ascending)
+//   | routine of every sphere [n_spheres] u8 = min(GpuMaterial.id, 4): what a scatter step switches on
+//   | 8-byte aligned: cell table [ncells] of two u32 = {first further item | item count << 16, id0 | id1 << 16}: the first two sphere ids
+//     of a cell arrive WITH its entry, so their records are one LDS round trip away (entry -> records) instead of two (entry -> ids ->
+//     records) -- most cells list at most two spheres (RTIOW: 0.84 tests per visited cell) -- round 4, -2 % on RTIOW
 //   | 16-byte aligned: test records {cx, cy, cz, r^2} of the big spheres [n_big], in list order (a COPY: the always-tested list
 //     needs no id -> record indirection) | of EVERY sphere [n_spheres], by sphere id.
-// A record is the first half of the sphere's PreparedSphere.  A cell's item test reads the id, then the record: two dependent
-// LDS reads.  (Round 2 stored a record per list ENTRY -- one round trip, but a sphere listed in k cells stored k times, 17 KB for
-// RTIOW; stored once per sphere the blob is 8 KB smaller, the pools grow by 8 slots per wave, and -- what pays -- the cells can
-// be made smaller without the blob outgrowing LDS: cell = 2.5 median radii instead of 4, -9 % on RTIOW.)
+// A record is the first half of the sphere's PreparedSphere.  (Round 2 stored a record per list ENTRY -- a sphere listed in k cells stored
+// k times, 17 KB for RTIOW; stored once per sphere the cells can be made smaller without the blob outgrowing LDS: cell = 2.5 median radii
+// instead of 4, -9 % on RTIOW.)
 struct GridHeader {
     float    org[3];        // lower corner
     float    cell[3];       // cell size per axis
@@ -72,6 +76,10 @@ struct GridHeader {
     uint32_t off_ops;       // BYTE offset of the per-sphere routine-queue table
     uint32_t off_big_recs;  // BYTE offsets (multiples of 16) of the test records: the big spheres' copies ...
     uint32_t off_recs;      // ... and every sphere's, by id
+    uint32_t n_entries;     // cell entries in total (a sphere counts once per cell that lists it)
+    float    inv_dim_x;     // 1 / dims[0] and 1 / (dims[0] * dims[1]), IEEE quotients from the host: a parked walk's linear cell index is
+    float    inv_dim_xy;    // taken apart with them (floor((n + 0.5) * inv) == n / d exactly for n, d <= 8192: tests/test_abi.py)
+    uint32_t pad_;
 };
 static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte copies");
 #ifndef MIRT_DISPENSER_STRIDE
@@ -103,8 +111,17 @@ constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many sampl
 // is staged once for all 16 waves and the rest of the 160 KB goes to the path pools.  Measured on RTIOW 1080p x 128 spp:
 // 512 threads x 112 slots, two blocks 17.3 ms; x 128 slots 16.6; 1024 x 144 15.9; 1024 x 152 15.7; one 512-thread
 // block per CU (8 waves) with 160-256 slots 26.3 -- the pools want to be as large as 16 resident waves allow.
-constexpr uint32_t kGridPoolThreads = 1024;
-constexpr uint32_t kGridPoolSlotChoices[4] = { 160, 152, 128, 96 };   // the largest geometry whose block fits LDS is taken
+// (experiment builds: -DMIRT_GRID_THREADS=640 -DMIRT_GRID_BLOCKS=2 -DMIRT_GRID_MINW=5 "-DMIRT_GRID_SLOTS=104,96,88,80" = 20 waves per CU)
+#ifndef MIRT_GRID_THREADS
+#define MIRT_GRID_THREADS 1024
+#define MIRT_GRID_BLOCKS 1
+#define MIRT_GRID_MINW 4
+#define MIRT_GRID_SLOTS 160, 152, 128, 96
+#endif
+constexpr uint32_t kGridPoolThreads = MIRT_GRID_THREADS;
+constexpr uint32_t kGridPoolBlocksPerCu = MIRT_GRID_BLOCKS;    // blocks of the grid build that share a CU's LDS
+constexpr uint32_t kGridPoolMinWaves = MIRT_GRID_MINW;         // waves per SIMD the build is held to (launch bounds)
+constexpr uint32_t kGridPoolSlotChoices[4] = { MIRT_GRID_SLOTS };   // the largest geometry whose block fits LDS is taken
 // Samples per pixel from which the pooled kernel is the default (below: the strip kernel, lane = pixel).  A 16-pixel strip
 // of few samples cannot keep a pool full (about 25 steps of fill and drain per strip whatever it holds), so the thresholds are
 // measured crossovers (tools/ab_libs.py with MIRT_FLAG_KERNEL_STRIP / _POOL, 1080p):

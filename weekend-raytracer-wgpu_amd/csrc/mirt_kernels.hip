@@ -748,7 +748,7 @@ struct Stamps {
 struct GridLds {
     const GridHeader*     h;
     const unsigned short* big;        // ids of the big spheres
-    const uint32_t*       cells;      // per cell: first item | item count << 16
+    const uint2*          cells;      // per cell: {first FURTHER item | item count << 16, id0 | id1 << 16}: the first two ids arrive with the header
     const unsigned short* items;      // ids of the cells' items
     const unsigned char*  ops;        // routine queue of every sphere (PreparedSphere.op)
     const float4*         big_recs;   // {centre, r^2} of the big spheres, in list order
@@ -791,7 +791,7 @@ MIRT_DEV GridLds stage_grid(const RenderArgs& A, unsigned char* gdst)
     G.h = reinterpret_cast<const GridHeader*>(gdst);
     const unsigned short* base = reinterpret_cast<const unsigned short*>(gdst);
     G.big = base + G.h->off_big;
-    G.cells = reinterpret_cast<const uint32_t*>(gdst + G.h->off_cells);
+    G.cells = reinterpret_cast<const uint2*>(gdst + G.h->off_cells);
     G.items = base + G.h->off_items;
     G.ops = gdst + G.h->off_ops;
     G.big_recs = reinterpret_cast<const float4*>(gdst + G.h->off_big_recs);
@@ -814,6 +814,30 @@ MIRT_DEV void test_big_spheres(const GridLds& G, f3 ro, f3 rd, float a, float in
         test_sphere<COUNT>(r3, i3, ro, rd, a, inv_a, alive, closest, best, work);
     }
     for (; j < n_big; ++j) test_sphere<COUNT>(G.big_recs[j], G.big[j], ro, rd, a, inv_a, alive, closest, best, work);
+}
+
+// A cell's items from its table entry `cw` (count = 0 for lanes that are not walking): the first two ids came with the entry, so their
+// records are ONE round trip away (entry -> records) instead of two (entry -> ids -> records) -- and most cells list at most two
+// spheres (RTIOW: 0.84 tests per visited cell).  Further items as before: ids, then records, two per round trip.
+template <bool COUNT>
+MIRT_DEV void test_cell_entry(const GridLds& G, uint2 cw, uint32_t count, f3 ro, f3 rd, float a, float inv_a, float& closest, int& best, Work<COUNT>& work)
+{
+    const uint32_t first = cw.x & 0xffffu;
+    {
+        const bool on0 = count > 0u, on1 = count > 1u;
+        const uint32_t i0 = cw.y & 0xffffu, i1 = cw.y >> 16;                 // absent ids are stored as 0: a valid record, not tested
+        const float4 r0 = G.recs[i0], r1 = G.recs[i1];
+        if (ballot_(on0)) test_sphere<COUNT>(r0, i0, ro, rd, a, inv_a, on0, closest, best, work);
+        if (ballot_(on1)) test_sphere<COUNT>(r1, i1, ro, rd, a, inv_a, on1, closest, best, work);
+    }
+    for (uint32_t n = 2; ballot_(n < count); n += 2) {
+        const bool on0 = n < count, on1 = n + 1 < count;
+        const uint32_t k0 = on0 ? first + n - 2u : 0u, k1 = on1 ? first + n - 1u : 0u;
+        const uint32_t i0 = G.items[k0], i1 = G.items[k1];
+        const float4 r0 = G.recs[i0], r1 = G.recs[i1];
+        test_sphere<COUNT>(r0, i0, ro, rd, a, inv_a, on0, closest, best, work);
+        if (ballot_(on1)) test_sphere<COUNT>(r1, i1, ro, rd, a, inv_a, on1, closest, best, work);
+    }
 }
 
 // the items [first, first + count) of each lane's cell, two records in flight per LDS round trip
@@ -885,13 +909,13 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
     while (ballot_(walking)) {
         uint32_t first = 0, count = 0;
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
-        if (walking) {
-            const uint32_t c = (uint32_t)((cz * dy + cy) * dx + cx);
-            const uint32_t cw = G.cells[c];
-            first = cw & 0xffffu;
-            count = cw >> 16;
+        {
+            const uint32_t c = walking ? (uint32_t)((cz * dy + cy) * dx + cx) : 0u;
+            const uint2 cw = G.cells[c];
+            count = walking ? cw.x >> 16 : 0u;
+            (void)first;
+            test_cell_entry<COUNT>(G, cw, count, ro, rd, a, inv_a, closest, best, work);
         }
-        test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
         {   // one DDA step, branch-free (see grid_walk)
             const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
             const bool stop = (closest <= t_exit) | (t_exit > tmax);        // nearest hit is final, or the ray left the grid
@@ -969,7 +993,12 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         cz = cz < 0 ? 0 : (cz >= dz ? dz - 1 : cz);
     } else {
         walking = active;
-        cx = (int)(cellp & 1023u); cy = (int)((cellp >> 10) & 1023u); cz = (int)((cellp >> 20) & 1023u);
+        // the parked LINEAR index taken apart: floor((n + 0.5) * (1 / d)) == n / d exactly for n, d <= 8192
+        const int nxy = dx * dy;
+        cz = (int)(((float)cellp + 0.5f) * H.inv_dim_xy);
+        const int rem = (int)cellp - cz * nxy;
+        cy = (int)(((float)rem + 0.5f) * H.inv_dim_x);
+        cx = rem - cy * dx;
     }
     const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
     // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
@@ -980,38 +1009,37 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
     const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
     const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
 
+    // linear cell index, advanced with the walk (one multiply-add pair per WALK instead of per cell; the strides are selects)
+    uint32_t cidx = (uint32_t)((cz * dy + cy) * dx + cx);
+    const int stride_y = sy > 0 ? dx : -dx, stride_z = sz > 0 ? dx * dy : -(dx * dy);
     if (resume) stamps.mark(7); else stamps.mark(4);
     // (Letting an instalment run past its budget while most lanes are still walking was measured: the fuller instalments gain 1-2 %,
     //  but the loop header it needs -- ballot, population count and two compares instead of `it < budget && any` -- costs this loop 5 %.)
     // (The budget is a compile-time constant when both kinds of instalment have the same one, and the loop is then unrolled: a
     //  run-time bound -- different budgets for fresh and resumed walks -- was measured 5 % slower at every pair of values tried.)
+    // Software-pipelined walk: the DDA step does not depend on the sphere tests (only `stop` does), so the NEXT cell's table entry is
+    // requested before the current cell's records are tested -- one exposed LDS round trip per cell (the records) instead of two.
+    uint2 cw = G.cells[walking ? cidx : 0u];
 #pragma unroll
     for (uint32_t it = 0; it < budget && ballot_(walking); ++it) {
-        uint32_t first = 0, count = 0;
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
-        {   // no exec-mask region: lanes that are not walking read cell 0 and take no items
-            const uint32_t c = walking ? (uint32_t)((cz * dy + cy) * dx + cx) : 0u;
-            const uint32_t cw = G.cells[c];
-            first = cw & 0xffffu;
-            count = walking ? cw >> 16 : 0u;
-        }
-        test_cell_items<COUNT>(G, first, count, ro, rd, a, inv_a, closest, best, work);
-        {   // one DDA step, branch-free: mask logic and selects (lanes that are not walking compute along, unused).  The nested
-            // if / else-if chain this replaces cost ~25 scalar instructions per cell in exec-mask bookkeeping: -3.1 % on RTIOW;
-            // the clip above and the cell-header read without exec regions: another -1.7 %.
-            const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
-            const bool stop = (closest <= t_exit) | (t_exit > tmax);        // nearest hit is final, or the ray left the grid
-            const bool ax = (tx <= ty) & (tx <= tz);
-            const bool ay = !ax & (ty <= tz);
-            const bool az = !ax & !ay;
-            cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
-            tx = ax ? tx + ddx : tx; ty = ay ? ty + ddy : ty; tz = az ? tz + ddz : tz;
-            const bool inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cy < (uint32_t)dy) & ((uint32_t)cz < (uint32_t)dz);
-            walking = walking & !stop & inside_grid;
-        }
+        const uint32_t count = walking ? cw.x >> 16 : 0u;
+        const uint2 cw_now = cw;
+        const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
+        const bool ax = (tx <= ty) & (tx <= tz);
+        const bool ay = !ax & (ty <= tz);
+        const bool az = !ax & !ay;
+        cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
+        cidx += (uint32_t)(ax ? sx : (ay ? stride_y : stride_z));
+        tx = ax ? tx + ddx : tx; ty = ay ? ty + ddy : ty; tz = az ? tz + ddz : tz;
+        const bool inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cy < (uint32_t)dy) & ((uint32_t)cz < (uint32_t)dz);
+        const bool may_go_on = walking & inside_grid & !(t_exit > tmax);
+        if (it + 1 < budget) cw = G.cells[may_go_on ? cidx : 0u];                // in flight while the tests below run
+        test_cell_entry<COUNT>(G, cw_now, count, ro, rd, a, inv_a, closest, best, work);
+        walking = may_go_on & !(closest <= t_exit);                              // the nearest hit is final once it lies inside the cells visited
     }
     if (resume) stamps.mark(8); else stamps.mark(5);
-    cellp = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);      // meaningful where `walking` is still set
+    cellp = cidx;                                                             // meaningful where `walking` is still set
 }
 
 MIRT_DEV f3 rand_in_unit_sphere(Rng& rng)     // wgsl:480-491
@@ -1175,6 +1203,88 @@ MIRT_DEV Scattered shade_by_id(const RenderArgs& A, const M& m, uint32_t id, boo
     case 2u: if (counted) work.add(kCntScatter2); shade_dielectric(m, rd, hn, rng, ndir, att); break;
     case 3u: if (counted) work.add(kCntScatter3); shade_checkerboard(A, m, hp, hn, rng, ndir, att); break;
     default: if (counted) work.add(kCntScatter4); shade_missing(hn, rng, ndir, att); break;
+    }
+    return Scattered{ ndir, att };
+}
+
+// Pool kernel, grid build: scatterRay's switch with everything a hit needs arriving as late as it is needed.  The routine id and the
+// sphere's centre come from LDS (GridLds.ops / recs, the tables the trace reads anyway), so the switch and the routines' random draws --
+// which need neither the normal nor the material -- run while the two 16-byte global loads of the ShadeRec (`ra` = {1/r, x, 1/x, flags},
+// `t0` = first texture; the checkerboard's second texture is a third load inside its case) are still in flight.  Same arithmetic in the
+// same order of RNG draws as shade_by_id: the routines only take their normal later.
+template <bool COUNT>
+MIRT_DEV Scattered shade_grid_hit(const RenderArgs& A, uint32_t id, const float4* rec, const float4 ra, const float4 t0, f3 centre, bool counted,
+                                  f3 rd, f3 hp, Rng& rng, Work<COUNT>& work)
+{
+    f3 ndir = rd, att = mk(1, 1, 1);
+    switch (id) {
+    case 0u: {
+        if (counted) work.add(kCntScatter0);
+        // scatter_lambertian with the normal taken after the draws
+        const float phi = rng.next_scaled(kTwoPi * 0x1p-32f);
+        const float r2 = rng.next();
+        const float sqrt_r2 = sqrt_unit(r2);
+        const float z = sqrt_unit(1.0f - r2);
+        const SinCos sc = sincos_small(phi);
+        const float lx = sc.c * sqrt_r2;
+        const float ly = sc.s * sqrt_r2;
+        const f3 n = ra.x * (hp - centre);
+        const MatRegs m{ 0u, ra.y, ra.z, bits(ra.w), t0, t0 };
+        const float sg = (n.z >= 0.0f) ? 1.0f : -1.0f;
+        const float aa = -rcp_in_range(sg + n.z);
+        const float bb = n.x * n.y * aa;
+        const f3 U = mk(fma_(sg * n.x, n.x * aa, 1.0f), sg * bb, -(sg * n.x));
+        const f3 V = mk(bb, fma_(n.y, n.y * aa, sg), -n.y);
+        const f3 wi = fma3(z, n, fma3(ly, V, lx * U));
+        const float dn = dot(n, wi);
+        const float dnc = dn * kFrac1Pi;
+        float kk = 1.0f;
+        const bool grazing = !(dnc > kEpsilon);
+        if (__builtin_expect(ballot_(grazing) != 0ull, 0)) {
+            asm volatile("; shade_grid_hit: grazing direction" ::);
+            if (grazing) kk = (kFrac1Pi * max_(kEpsilon, dn)) / max_(kEpsilon, dnc);
+        }
+        att = albedo_at(A, m, 0, n);
+        if (__builtin_expect(ballot_(grazing) != 0ull, 0)) {
+            asm volatile("; shade_grid_hit: grazing attenuation" ::);
+            att = kk * att;
+        }
+        ndir = wi;
+        break;
+    }
+    case 1u: {
+        if (counted) work.add(kCntScatter1);
+        const f3 rs = rand_in_unit_sphere(rng);                 // the draws first: they need neither normal nor material
+        const f3 n = ra.x * (hp - centre);
+        const MatRegs m{ 1u, ra.y, ra.z, bits(ra.w), t0, t0 };
+        const f3 refl = reflect3(rd, n);
+        ndir = fma3(mat_x(m), rs, refl);
+        att = albedo_at(A, m, 0, n);
+        break;
+    }
+    case 2u: {
+        if (counted) work.add(kCntScatter2);
+        const f3 n = ra.x * (hp - centre);
+        const MatRegs m{ 2u, ra.y, ra.z, bits(ra.w), t0, t0 };
+        shade_dielectric(m, rd, n, rng, ndir, att);
+        break;
+    }
+    case 3u: {
+        if (counted) work.add(kCntScatter3);
+        const float4 t1 = rec[2];
+        const f3 n = ra.x * (hp - centre);
+        const MatRegs m{ 3u, ra.y, ra.z, bits(ra.w), t0, t1 };
+        shade_checkerboard(A, m, hp, n, rng, ndir, att);
+        break;
+    }
+    default: {
+        if (counted) work.add(kCntScatter4);
+        const f3 rs = rand_in_unit_sphere(rng);
+        const f3 n = ra.x * (hp - centre);
+        ndir = n + rs;
+        att = mk(0.9921f, 0.24705f, 0.57254f);
+        break;
+    }
     }
     return Scattered{ ndir, att };
 }
@@ -1555,7 +1665,7 @@ struct WavePoolLayout {
     static constexpr uint32_t kOffState = 0;                                  // [SLOTS][3] uint4
     static constexpr uint32_t kOffAcc   = kOffState + SLOTS * 48;             // [kStripPixels][3] u64
     static constexpr uint32_t kOffCell  = kOffAcc + kStripPixels * 3 * 8;     // [SLOTS] u32: grid cell of a path whose walk is cut (GRID)
-    static constexpr uint32_t kOffRing  = kOffCell + (GRID ? SLOTS * 4 : 0);  // [kQueues][kRing] u8
+    static constexpr uint32_t kOffRing  = kOffCell + (GRID ? SLOTS * 2 : 0);  // ([SLOTS] u16 cells: the LINEAR index of a parked walk's cell)  [kQueues][kRing] u8
     static constexpr uint32_t kOffCand  = ((kOffRing + kQueues * kRing + 15) / 16) * 16;     // camera-ray candidates of the strip (GRID): ids + count
     static constexpr uint32_t kOffTile  = kOffCand + (GRID ? kCandBytes : 0);                // TexelTile: header + 3 colour planes (TILE)
     static constexpr uint32_t kBytes    = kOffTile + (TILE ? ((kTileBytes + 15) / 16) * 16 : 0);
@@ -1830,16 +1940,16 @@ static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bo
     }
 #endif
     if (slots == kGridPoolSlotChoices[0])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 4, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 4, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
     if (slots == kGridPoolSlotChoices[1])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 4, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
     if (slots == kGridPoolSlotChoices[2])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], 4, false, false, 1, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], 4, false, true, 1, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], 4, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
@@ -1923,7 +2033,7 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     const char* tf[2] = { "false", "true" };
     uint32_t slots = 112, minw = 6, threads = 256;
-    if (a.grid) { threads = kGridPoolThreads; slots = a.grid_pool_slots; minw = count ? 1 : 4; nq = 1; }
+    if (a.grid) { threads = kGridPoolThreads; slots = a.grid_pool_slots; minw = count ? 1 : kGridPoolMinWaves; nq = 1; }
     else {
         switch (cfg) {
         case 1: slots = 128; minw = 1; break;
