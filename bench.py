@@ -21,8 +21,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 figures of SURVEY §8d / DESIGN.md) / the kernel's average duration measured with HIP events on
                 the launch stream inside the timed region.
   cpu_baseline  the CPU oracle (a port: the reference is Rust and cannot be built here) timed on the host cores
-                on a bounded sample of the same workload (rank 0, N = 1 only; best of 3 runs with bound OpenMP
-                threads, `median` / `min` beside it), plus `layer_rs`: the reference's
+                on a bounded sample of the same workload (rank 0, N = 1 only; best of 3 runs on as many threads as
+                the cgroup's CPU quota allows, `median` / `min` beside it), plus `layer_rs`: the reference's
                 own CPU loop (`Layer::set_data`, parity mode) restated, faithful (with its per-sample
                 world.clone() allocations) and clean, on 1 thread and on all cores.
   verified_rows rows of the frame the timed region produced -- for N > 1 the frame GATHERED over RCCL on rank 0 --
@@ -239,8 +239,10 @@ def cpu_baseline(m, sd, cfg: dict, target_seconds: float = 12.0, repeats: int = 
         return {"value": best["msamples_per_s"], "unit": "Msamples/s", "cores": cores, "kind": "port",
                 "sample": f"Layer::scene {w}x{h} at {lr['spp']} spp (the reference's default), clean variant on all cores; see layer_rs",
                 "layer_rs": lr}
-    # calibrate on a small sample, then REPEATS runs of ~target_seconds / REPEATS each: the host's rate wanders by +-14 % from one
-    # un-repeated sample to the next (256 threads, other tenants, first-touch page placement); the best of N is reproducible
+    # calibrate on a small sample, then REPEATS runs of ~target_seconds / REPEATS each: round 3's single sample on 256 threads (the
+    # host's logical CPUs; the job's cgroup quota is 16) wandered by +-14 % from run to run.  host_cores() now honours the quota,
+    # and the best of N is what is reported.  (Binding the threads with OMP_PROC_BIND was tried: it pins the MAIN thread too, after
+    # which the affinity mask says one CPU.)
     spp, secs = 4, 0.0
     per_run = target_seconds / repeats
     for _ in range(3):
@@ -259,9 +261,8 @@ def cpu_baseline(m, sd, cfg: dict, target_seconds: float = 12.0, repeats: int = 
     best, median = rates[-1], rates[len(rates) // 2]
     return {"value": round(best, 3), "unit": "Msamples/s", "cores": cores,
             "kind": "port", "repeats": repeats, "median": round(median, 3), "min": round(rates[0], 3),
-            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
             "sample": f"same scene and frame ({w}x{h}, {BOUNCES} bounces) at {spp} spp instead of {full}, best of {repeats} runs "
-                      f"({min(runs):.1f} s each; rate is spp-independent); oracle = C restatement, OpenMP over rows, threads bound; "
+                      f"({min(runs):.1f} s each; rate is spp-independent); oracle = C restatement, OpenMP over rows, one thread per CPU of the cgroup's quota; "
                       f"the Rust reference cannot be built (no toolchain)"}
 
 
@@ -635,13 +636,6 @@ def main(argv=None) -> int:
         return 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)                       # BEFORE torch / the GPU are touched in this process
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ:
-        # cpu_baseline's OpenMP threads stay where they start (a reproducible baseline); must be in the environment before the
-        # first OpenMP runtime of the process initialises, i.e. before torch is imported.  One process only: N ranks would all
-        # bind to the same places.
-        os.environ.setdefault("OMP_PROC_BIND", "close")
-        os.environ.setdefault("OMP_PLACES", "threads")
-
     import torch
     import torch.distributed as dist
 

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define MIRT_VERSION_MAJOR 0
-#define MIRT_VERSION_MINOR 3
+#define MIRT_VERSION_MINOR 4
 #define MIRT_VERSION_PATCH 0
 
 /* ------------------------------------------------------------------------------------------

@@ -86,5 +86,5 @@ def test_the_8_gpu_headline_job_verifies_its_gathered_frame_without_the_oracle()
 def test_cpu_baseline_is_a_best_of_n():
     d = _bench("--config", "2", "--steps", "2", "--warmup", "1")
     cb = d["cpu_baseline"]
-    assert cb["repeats"] >= 3 and cb["min"] <= cb["median"] <= cb["value"] and cb["omp"]["OMP_PROC_BIND"]
+    assert cb["repeats"] >= 3 and cb["min"] <= cb["median"] <= cb["value"] and cb["cores"] >= 2
     assert all(v["against"] == "oracle" and v["equal"] for v in d["verified_rows"])

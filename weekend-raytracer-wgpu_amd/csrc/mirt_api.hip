@@ -1005,7 +1005,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // the same at 3840x2160 3.20 / 2.96 / 2.89, at 800x600 0.71 / 0.41 / 0.33 -- and one more for many-sphere scenes (RTIOW 8 spp:
         // 1.54 / 1.40).  The samples must divide evenly; never with the reference's per-frame stream (sequentially dependent samples).
         if (pt && !frame_stream && tune.px_groups != 0) {
-            const uint32_t min_share = use_grid ? 4u : 8u;
+            // (round 4, profiles/r04_lowspp_ab.txt: three spheres at 12 spp, two groups of 6: 0.486 ms against 0.529 for one group of 12 -> shares of >= 6)
+            const uint32_t min_share = use_grid ? 4u : 6u;
             while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= min_share)
                 a.px_groups_log2 += 1u;
             if (tune.px_groups > 0 && p->spp % (1u << (tune.px_groups - 1)) == 0u) a.px_groups_log2 = (uint32_t)tune.px_groups - 1u;
@@ -1015,6 +1016,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // always -- its lane = pixel units are a few dozen sphere tests each, and one dispenser atomic per unit (14 ns, serialised on
         // its address) was the whole kernel time: 7 500 units of an 800x600 frame at 2 spp 94 us whatever the work
         a.static_units = (!pt || p->spp < 4u) ? 1u : 0u;  // (three spheres 1080p: 2 spp 0.132 ms dealt / 0.169 dispensed, 4 spp 0.244 / 0.234)
+        // 4 spp in flat scenes: 32-pixel units with two sample groups of 2, dealt round-robin (three spheres 0.219 ms against 0.227 dispensed
+        // 64-pixel units and 0.240 dealt ones; main.rs scene 0.297 / 0.300; profiles/r04_lowspp_ab.txt)
+        if (pt && !frame_stream && !use_grid && p->spp == 4u && tune.px_groups < 0 && tune.static_units < 0) {
+            a.static_units = 1u;
+            a.px_groups_log2 = 1u;
+            a.n_units = (uint32_t)((npix + 31u) / 32u);
+        }
         if (tune.static_units >= 0) a.static_units = (uint32_t)tune.static_units;
     }
 
