@@ -90,14 +90,7 @@ def _grid_plan(spheres, lds=0):
     return out
 
 
-def bimodal_soup(seed=0, n_small=1300, n_medium=1100, r=0.05, extent_radii=20.0):
-    """A soup whose spheres are either r or 3.9 r (just under the 4-median-radii limit of the grid): at the default cell of 2.5
-    median radii a medium sphere spans 4-5 cells per axis and the lists overflow their 16-bit index; at 4 they do not."""
-    import numpy as np
-    rng = np.random.default_rng(seed)
-    rs = np.concatenate([np.full(n_small, r), np.full(n_medium, 3.9 * r)]).astype(np.float32)
-    cs = rng.uniform(-extent_radii * r, extent_radii * r, (n_small + n_medium, 3)).astype(np.float32)
-    return cs, rs
+from helpers import bimodal_soup  # noqa: E402
 
 
 def _entries_at(cs, rs, factor):

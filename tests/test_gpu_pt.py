@@ -494,6 +494,25 @@ def test_camera_ray_candidate_lists(gpu_ctx, oracle, case):
         assert st[k] == want_counts[k], (k, st[k], want_counts[k])
 
 
+def test_a_scene_whose_lists_overflow_at_the_default_cell_keeps_its_grid(gpu_ctx, oracle):
+    """a bimodal soup (half the spheres just under 4 median radii) lists more than 65 535 entries at the default cell of
+    2.5 median radii; the builder retries coarser instead of falling back to the flat scan (tests/test_abi.py holds the plan).  The
+    blob leaves no room for path pools, so the strip kernel's grid build renders it -- and must give the oracle's flat-scan image."""
+    from helpers import bimodal_soup
+    cs, rs = bimodal_soup()
+    mats, tex = m.flatten_materials([m.Material.Lambertian(albedo=m.Texture.new_from_color((0.6, 0.5, 0.4))),
+                                     m.Material.Metal(albedo=m.Texture.new_from_color((0.8, 0.8, 0.9)), fuzz=0.1),
+                                     m.Material.Dielectric(refraction_index=1.5)])
+    spheres = [m.Sphere.new(tuple(float(x) for x in c), float(r), i % 3).to_c() for i, (c, r) in enumerate(zip(cs, rs))]
+    w, h = 64, 36
+    sd = m.SceneData(simple_camera(w, h, eye=(0.0, 0.3, 3.0), direction=(0.0, -0.05, -1.0)), spheres, mats, tex)
+    gpu_ctx.set_scene(sd)
+    p = m.make_params(w, h, 4, mode=m.MIRT_MODE_PT, num_bounces=4)
+    got = gpu_ctx.render(p)
+    assert gpu_ctx.last_kernel().startswith("render_pt_strip_kernel<false,false,true,"), gpu_ctx.last_kernel()      # GRID = true
+    assert_images_equal(got, oracle.render(sd, p), "bimodal soup through the grid at cell = 4")
+
+
 def test_grid_with_rays_parallel_to_axes(gpu_ctx, oracle):
     """Axis-aligned rays (zero direction components) through the grid: the DDA's 1/0 handling."""
     rng = np.random.default_rng(77)
