@@ -19,7 +19,7 @@ def test_algorithmic_flops_formula():
 def test_profiled_traffic_lookup_matches_committed_summaries():
     # the headline kernel under the name mirt_ctx_last_kernel reports (this round's summaries) ...
     new = bench.profiled_traffic("render_pt_pool_kernel<256,112,6,false,false,3,false>", bench.CONFIGS["3"]["workload"])
-    assert new is not None and new[1].startswith("r03") and 8.29e6 <= new[0] <= 2 * 8.3e6      # the newest committed summary wins
+    assert new is not None and new[1].startswith("r04_c3_pmc") and 8.29e6 <= new[0] <= 2 * 8.3e6      # the newest committed summary OF THIS WORKLOAD wins (not the 2-spp runs of the same kernel family)
     # ... and round 1's summaries under the name bench.py used then
     got = bench.profiled_traffic("render_pt_pool_kernel<256,112,false,false>")
     assert got is not None
