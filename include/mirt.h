@@ -249,7 +249,7 @@ typedef enum MirtStatus {
      *   flat layout (every mode and flag): 96 + 32 * n_spheres + 48 * n_materials + 144 <= 122 880 bytes
      *       -- e.g. 3 831 spheres with one material;
      *   grid layout (MIRT_MODE_PT only, scenes of >= 32 spheres of which at most 64 exceed 4 median radii): n_spheres <= 4 095
-     *       (12-bit sphere ids in a path's state word), <= 8 192 cells and <= 65 535 cell entries (the host starts at a cell of
+     *       (12-bit sphere ids in a path's state word), <= 4 096 cells and <= 65 535 cell entries (the host starts at a cell of
      *       2.5 median radii and coarsens it, x 1.26 per step up to 4, while either limit is exceeded or the blob would cost the
      *       pooled kernel its 152-slot geometry), and 240 + blob <= 122 880 bytes with blob ~ 17 * n_spheres + 4 * cells +
      *       2 * entries.  Grids with a dimension above 1 024 cells (10-bit cell coordinates) run the strip kernel instead of

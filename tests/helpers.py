@@ -91,7 +91,7 @@ def full_frame_bands(h: int, seconds_per_row_thread: float, cores: int, budget_s
     return [(s0, s0 + band) for s0 in sorted(set(starts))]
 
 
-def bimodal_soup(seed=0, n_small=1300, n_medium=1100, r=0.05, extent_radii=20.0):
+def bimodal_soup(seed=0, n_small=1300, n_medium=1100, r=0.05, extent_radii=16.0):
     """A soup whose spheres are either r or 3.9 r (just under the 4-median-radii limit of the grid): at the default cell of 2.5
     median radii a medium sphere spans 4-5 cells per axis and the lists overflow their 16-bit index; at 4 they do not."""
     import numpy as np

@@ -70,6 +70,36 @@ class OracleError(RuntimeError):
         super().__init__(self.status_name)
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota (a GPU box gives a one-GPU job 16 of its 256
+    logical CPUs: 256 OpenMP threads on that quota run the oracle at half the rate of 16)."""
+    import os
+    from pathlib import Path
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                    # cgroup v2
+        q, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+DEFAULT_THREADS = host_cores()       # n_threads = 0 in the calls below: one thread per usable CPU, not OpenMP's one per logical CPU
+
+
 def out_rows(params) -> int:
     return int(LIB.mirt_params_out_rows_impl(C.byref(params)))
 
@@ -83,7 +113,7 @@ def render(scene: "mirt.SceneData", params, n_threads: int = 0, variant: int = C
     rows = out_rows(params)
     out = np.zeros((rows, params.width, 4), dtype=np.uint8)
     c = scene.as_c()
-    rc = LIB.mirt_oracle_render(C.byref(c), C.byref(params), out.ctypes.data_as(C.c_void_p), out.nbytes, n_threads, variant)
+    rc = LIB.mirt_oracle_render(C.byref(c), C.byref(params), out.ctypes.data_as(C.c_void_p), out.nbytes, n_threads or DEFAULT_THREADS, variant)
     if rc != 0:
         raise OracleError(rc)
     return out
@@ -100,7 +130,7 @@ def render_pt_sums(scene: "mirt.SceneData", params, n_threads: int = 0) -> np.nd
     rows = out_rows(params)
     out = np.zeros((rows, params.width, 3), dtype=np.uint64)
     c = scene.as_c()
-    rc = LIB.mirt_oracle_render_pt_sums(C.byref(c), C.byref(params), out.ctypes.data_as(C.c_void_p), out.size, n_threads)
+    rc = LIB.mirt_oracle_render_pt_sums(C.byref(c), C.byref(params), out.ctypes.data_as(C.c_void_p), out.size, n_threads or DEFAULT_THREADS)
     if rc != 0:
         raise OracleError(rc)
     return out

@@ -99,7 +99,7 @@ def _entries_at(cs, rs, factor):
     cs, rs = cs.astype(np.float64), rs.astype(np.float64)
     cell = factor * np.sort(rs)[len(rs) // 2]
     lo, hi = (cs - rs[:, None]).min(0), (cs + rs[:, None]).max(0)
-    while np.prod(np.maximum(1, np.ceil((hi - lo) / cell + 1e-6))) > 8192:
+    while np.prod(np.maximum(1, np.ceil((hi - lo) / cell + 1e-6))) > 4096:
         cell *= 1.26
     dims = np.maximum(1, np.ceil((hi - lo) / cell + 1e-6)).astype(int)
     eps = 1e-3 * cell
@@ -112,7 +112,7 @@ def test_grid_plan_of_the_rtiow_scene():
     scene, _ = m.scenes.rtiow_final()
     g = _grid_plan([s.to_c() for s in scene.spheres])
     assert g.cell_factor == 2.5 and g.n_big == 4 and g.pool_slots == 152            # ground + the three r = 1 spheres stay outside the grid
-    assert 0 < g.blob_bytes < 26 * 1024 and g.n_cells <= 8192 and 0 < g.n_entries < 65536         # 24 640 B: two u32 per cell since round 4
+    assert 0 < g.blob_bytes < 26 * 1024 and g.n_cells <= 4096 and 0 < g.n_entries < 65536         # 24 640 B: two u32 per cell since round 4
     assert _grid_plan([s.to_c() for s in scene.spheres[:20]]).cell_factor == 0.0      # fewer than 32 spheres: no grid
 
 
@@ -133,7 +133,7 @@ def test_grid_plan_coarsens_past_an_entry_overflow():
 
 def test_parked_cell_indices_come_apart_exactly():
     """A cut grid walk parks its LINEAR cell index (16 bit); the kernel takes it apart with float reciprocals computed on the host
-    (GridHeader.inv_dim_x / inv_dim_xy): floor((n + 0.5) * fl(1 / d)) == n // d for every n, d <= 8192 (kGridMaxCells)."""
+    (GridHeader.inv_dim_x / inv_dim_xy): floor((n + 0.5) * fl(1 / d)) == n // d for every n, d <= 8192 (kGridMaxCells is 4 096)."""
     import numpy as np
     n = np.arange(8192, dtype=np.float32) + np.float32(0.5)
     whole = np.arange(8192) 

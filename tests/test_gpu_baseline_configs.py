@@ -124,7 +124,7 @@ def test_complete_frames_at_the_full_sample_count_against_the_oracle(gpu_ctx, or
         assert np.array_equal(got[rb:rb + 1], oracle.render_pt_sums(sd, band, n_threads=1)), f"{name}: row {rb}"
     per_row_thread = (time.perf_counter() - t0) / len(probe_rows)
     budget = float(os.environ.get("MIRT_FULL_FRAME_BUDGET_S", "120"))
-    bands = full_frame_bands(h, per_row_thread, os.cpu_count() or 1, budget)
+    bands = full_frame_bands(h, per_row_thread, 2 * oracle.host_cores(), budget)          # (full_frame_bands halves its core count: SMT siblings)
     for first, last in bands:
         band = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, row_begin=first, row_end=last)
         want = oracle.render_pt_sums(sd, band)

@@ -86,7 +86,8 @@ static_assert(sizeof(GridHeader) % 16 == 0, "GridHeader is staged with 16-byte c
 #define MIRT_DISPENSER_STRIDE 1024           // u32 words between a launch's eight dispenser words: 4 KB, so that they sit in different memory channels
 #endif
 constexpr uint32_t kGridMinSpheres = 32;
-constexpr uint32_t kGridMaxCells   = 8192;
+constexpr uint32_t kGridMaxCells   = 4096;   // x 8 bytes per cell entry = the 32 KB of LDS that round 3's 8 192 four-byte entries could take: the pools keep their room
+                                            // (a soup of 700 small spheres over a wide volume lost every pool geometry to a 64 KB cell table: soak seed 3150)
 
 constexpr uint32_t kStripLevels   = 5;    // strip widths 16, 8, 4, 2, 1
 constexpr uint32_t kStripPixels   = 16;   // strip kernels: pixels one wave owns per work unit (64-B RGBA8 store)
