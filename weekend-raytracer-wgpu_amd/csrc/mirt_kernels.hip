@@ -1289,6 +1289,7 @@ MIRT_DEV Scattered shade_grid_hit(const RenderArgs& A, uint32_t id, const float4
     return Scattered{ ndir, att };
 }
 
+
 // radiance() wgsl:316-343, one channel of the Hosek-Wilkie state held in LDS
 MIRT_DEV float hosek_radiance(const float* sky, float theta, float gamma, int ch)
 {
