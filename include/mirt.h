@@ -252,8 +252,8 @@ typedef enum MirtStatus {
      *       (12-bit sphere ids in a path's state word), <= 4 096 cells and <= 65 535 cell entries (the host starts at a cell of
      *       2.5 median radii and coarsens it, x 1.26 per step up to 4, while either limit is exceeded or the blob would cost the
      *       pooled kernel its 152-slot geometry), and 240 + blob <= 122 880 bytes with blob ~ 17 * n_spheres + 8 * cells +
-     *       2 * (entries beyond the first two of each cell).  Grids with a dimension above 1 024 cells (10-bit cell coordinates) run the strip kernel instead of
-     *       the pooled one.  mirt_grid_plan() answers "which grid would this scene get" without a device.
+     *       2 * (entries beyond the first two of each cell).  A blob that leaves the pooled kernel no
+     *       room for its path pools (mirt_grid_plan: pool_slots = 0) runs the strip kernel's grid build.  mirt_grid_plan() answers "which grid would this scene get" without a device.
      * A scene that fits ONLY the grid layout renders in path-traced mode with default flags; a render call in parity mode, or
      * with MIRT_FLAG_COUNT_WORK without MIRT_FLAG_COUNT_GRID, or with MIRT_FLAG_NO_GRID, returns this code. */
     MIRT_ERR_SCENE_TOO_LARGE      = -18,
