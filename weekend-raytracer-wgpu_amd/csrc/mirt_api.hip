@@ -338,7 +338,7 @@ struct MirtContext {
     size_t cap_shade = 0;
     uint32_t grid_bytes = 0;
     bool     have_shade = false;             // d_shade holds this scene's records
-    bool     grid_packable = false;          // every grid dimension <= 1024: a cell fits the pool kernel's packed cell word
+    bool     grid_packable = false;          // the grid has at most kGridMaxCells cells: a parked walk's linear cell index fits 16 bits (always, as built)
     bool     fits_flat = true;               // spheres + materials fit the LDS budget (flat kernels usable)
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;

@@ -934,7 +934,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 
 // The same walk in instalments, for the pool kernel: a FRESH call tests the big spheres, clips the ray against the grid
 // and enters it; every call then visits at most `budget` cells per lane and reports the lanes that are not finished
-// (`walking`), whose state -- closest, best, the packed cell (x | y << 10 | z << 20) -- the pool keeps in the path's
+// (`walking`), whose state -- closest, best, the LINEAR index of the cell (16 bit) -- the pool keeps in the path's
 // slot until a later OP_WALK step RESUMES it.  Lanes finish after very different numbers of cells (3.4 on average on
 // the RTIOW scene, dozens for rays that graze the ground): cutting the walk into instalments lets the pool re-compact
 // the unfinished paths instead of idling the finished lanes (36 % lane use in the un-cut walk of nearest_hit_grid).
