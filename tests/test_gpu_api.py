@@ -407,6 +407,63 @@ def test_the_event_ring_wraps_with_launches_on_two_streams(oracle):
     ctx.close()
 
 
+def test_untimed_launches_render_the_same_frames_and_report_no_kernel_time(oracle):
+    """mirt_ctx_set_timing(0): launches carry no event unless the context must learn that they have finished (dispensed units: their
+    dispenser words are re-zeroed; counting launches).  Same frames; get_stats counts the launches and reports 0 ms; the ring still
+    wraps cleanly with dispensed launches on two streams; synchronize covers launches that carried no event at all."""
+    import torch
+    w, h = 640, 360
+    sd = scene_data("three_spheres", w, h)
+    ctx = m.Context(0)
+    ctx.set_scene(sd)
+    ctx.set_timing(False)
+    p2 = m.make_params(w, h, 2, mode=m.MIRT_MODE_PT)                                           # units dealt round-robin: no event at all
+    p8 = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3)                                   # dispensed units: an end event only
+    pp = m.make_params(w, h, 32, mode=m.MIRT_MODE_PT, seed=4, flags=m.MIRT_FLAG_KERNEL_POOL)   # pooled kernel, dispensed
+    want2, want8, wantp = oracle.render(sd, p2), oracle.render(sd, p8), oracle.render(sd, pp)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    b = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    c2 = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    ctx.stats()
+    for i in range(100):                                   # three wraps of the ring, two caller streams, dispensed launches without timing
+        check = i % 61 == 0 or i == 99
+        if check:
+            torch.cuda.synchronize()
+            a.fill_(0xAB)
+            b.fill_(0xAB)
+            torch.cuda.synchronize()
+        ctx.render_device(p8, a.data_ptr(), a.numel(), s1.cuda_stream)
+        ctx.render_device(pp, b.data_ptr(), b.numel(), s2.cuda_stream)
+        if check:
+            torch.cuda.synchronize()
+            assert np.array_equal(a.cpu().numpy(), want8), ("stream 1", i)
+            assert np.array_equal(b.cpu().numpy(), wantp), ("stream 2", i)
+    st = ctx.stats()
+    assert st["launches"] == 200 and st["kernel_ms_total"] == 0.0 and st["kernel_ms"] == 0.0
+    c2.fill_(0xAB)
+    torch.cuda.synchronize()
+    for _ in range(150):                                   # the reference's interactive frame: no event, no slot bookkeeping
+        ctx.render_device(p2, c2.data_ptr(), c2.numel(), s1.cuda_stream)
+    ctx.synchronize()                                      # no torch synchronisation: the context waits for the caller's stream itself
+    assert np.array_equal(c2.cpu().numpy(), want2)
+    assert ctx.stats()["launches"] == 150
+    # counting launches keep their end event (their counters are read afterwards), timing on again reports times again
+    pc = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3, flags=m.MIRT_FLAG_COUNT_WORK)
+    assert np.array_equal(ctx.render(pc), want8)
+    assert ctx.stats()["rays"] == oracle_counts(oracle, sd, pc)["rays"]
+    ctx.set_timing(True)
+    assert np.array_equal(ctx.render(p8), want8)
+    st = ctx.stats()
+    assert st["launches"] == 1 and st["kernel_ms_total"] > 0.0
+    ctx.close()
+
+
+def oracle_counts(oracle, sd, p):
+    oracle.render(sd, p)
+    return oracle.stats()
+
+
 def test_scene_limits_at_the_boundary(gpu_ctx):
     """include/mirt.h, MIRT_ERR_SCENE_TOO_LARGE: the flat layout holds 96 + 32 n + 48 m + 144 <= 122 880 bytes -- 3 831 spheres
     with one material --, the grid layout at most 4 095 spheres; a scene that fits only the grid layout renders in path-traced

@@ -5,6 +5,9 @@ Raytracer::set_render_params, layer.rs:188-193, mod.rs:353-388) and adds `num_sa
 a 2-spp render into device memory, queued back to back on one stream, 1920x1080, config-3 scene.
 
     python tools/interactive_step.py [frames]      -> prints one JSON object (also written to gpurun_out/)
+
+Both timing modes of the context (mirt_ctx_set_timing): ON = every launch carries an event pair (kernel times in the statistics),
+OFF = the frames carry no event at all (what a host that only displays the frames wants).
 """
 import json
 import sys
@@ -33,7 +36,10 @@ for i in range(8):                                        # a small orbit: a dif
 out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.Stream()
 res = {}
-for label, spp in (("2 spp per frame (reference default)", 2), ("1 spp per frame", 1), ("4 spp per frame", 4)):
+for timing in (True, False):
+  ctx.set_timing(timing)
+  mode = res.setdefault("timing on (default)" if timing else "timing off (mirt_ctx_set_timing(ctx, 0))", {})
+  for label, spp in (("2 spp per frame (reference default)", 2), ("1 spp per frame", 1), ("4 spp per frame", 4)):
     p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
     with torch.cuda.stream(stream):
         for i in range(20):                               # warm-up
@@ -49,10 +55,10 @@ for label, spp in (("2 spp per frame (reference default)", 2), ("1 spp per frame
         stream.synchronize()
         t_all = time.perf_counter() - t0
     st = ctx.stats()
-    res[label] = {"frames": frames, "host_issue_us_per_frame": round(1e6 * t_issue / frames, 2),
-                  "end_to_end_us_per_frame": round(1e6 * t_all / frames, 2),
-                  "kernel_us_per_frame_hip_events": round(1e3 * st["kernel_ms_total"] / max(1, st["launches"]), 2),
-                  "msamples_per_s_end_to_end": round(w * h * spp * frames / t_all / 1e6, 1), "kernel": ctx.last_kernel()}
+    mode[label] = {"frames": frames, "host_issue_us_per_frame": round(1e6 * t_issue / frames, 2),
+                   "end_to_end_us_per_frame": round(1e6 * t_all / frames, 2),
+                   "kernel_us_per_frame_hip_events": round(1e3 * st["kernel_ms_total"] / max(1, st["launches"]), 2) if timing else None,
+                   "msamples_per_s_end_to_end": round(w * h * spp * frames / t_all / 1e6, 1), "kernel": ctx.last_kernel()}
 print(json.dumps(res, indent=1))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "interactive_step.json").write_text(json.dumps(res, indent=1) + "\n")

@@ -38,14 +38,26 @@ p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT if a.mode == "pt" else m.MIRT
 out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.Stream()
 libs = []
-for path in a.libs:
+import os  # noqa: E402
+for spec in a.libs:                                       # lib.so@NAME=VALUE[,NAME=VALUE]: knobs read by mirt_ctx_create, as in ab_libs.py
+    path, _, envs = spec.partition("@")
     lib = C.CDLL(str(Path(path).resolve()))
     _abi.bind(lib, {k: v for k, v in _abi.SYMBOLS.items() if hasattr(lib, k)})
     ctx = C.c_void_p()
-    assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
+    knobs = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        assert lib.mirt_ctx_create(0, C.byref(ctx)) == 0, lib.mirt_last_error()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     sc = sd.as_c()
     assert lib.mirt_ctx_set_scene(ctx, C.byref(sc)) == 0, lib.mirt_last_error()
-    libs.append((Path(path).name, lib, ctx))
+    libs.append((Path(path).name + ("@" + envs if envs else ""), lib, ctx))
 wall = {n: [] for n, _, _ in libs}
 kern = {n: [] for n, _, _ in libs}
 for r in range(a.rounds + 1):
@@ -65,6 +77,6 @@ for r in range(a.rounds + 1):
             kern[name].append(1e3 * st.kernel_ms_total / max(1, st.launches))
 base = np.median(wall[libs[0][0]])
 for name, lib, ctx in libs:
-    print(f"{name:24s} wall per launch: median {np.median(wall[name]):9.2f} us  min {np.min(wall[name]):9.2f} us  {100 * np.median(wall[name]) / base:6.1f} %   "
+    print(f"{name:44s} wall per launch: median {np.median(wall[name]):9.2f} us  min {np.min(wall[name]):9.2f} us  {100 * np.median(wall[name]) / base:6.1f} %   "
           f"kernel (HIP events) {np.median(kern[name]):9.2f} us   {lib.mirt_ctx_last_kernel(ctx).decode()}")
     lib.mirt_ctx_destroy(ctx)

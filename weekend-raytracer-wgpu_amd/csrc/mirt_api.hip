@@ -242,6 +242,8 @@ struct Tuning {
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
+    int      timing = -1;             // MIRT_TIMING=0/1: the context's initial mirt_ctx_set_timing state (A/B runs; default 1)
+    bool     ext_events = true;       // MIRT_EXT_EVENTS=0: the event pair as two records in the stream instead of riding on the kernel dispatch (A/B runs)
 };
 
 Tuning read_tuning()
@@ -261,6 +263,8 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
+    if (const char* e = std::getenv("MIRT_TIMING")) t.timing = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_EXT_EVENTS")) t.ext_events = e[0] != '0';
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
     return t;
 }
@@ -309,6 +313,9 @@ struct MirtContext {
     std::vector<unsigned char> slot_dirty;        // the slot's launch took units from its dispenser words: they must be re-zeroed before the next use
     std::vector<unsigned char> slot_zeroing;      // a re-zeroing of the slot's dispenser words is queued (ev_zeroed says when it is done)
     std::vector<unsigned char> slot_zero_event;   // ... and which ev_zeroed: the slot's own, or its batch's first slot (retire_slots)
+    std::vector<unsigned char> slot_timed;        // the slot's launch carries a start AND an end event (kernel time is folded into the statistics)
+    bool        timing = true;                    // mirt_ctx_set_timing: launches carry an event pair (mirt_ctx_get_stats reports kernel times)
+    std::vector<hipStream_t> untimed_streams;     // caller streams that carried launches without an end event (mirt_ctx_synchronize covers them)
     size_t      ev_next = 0;          // slot of the next launch
     size_t      ev_in_flight = 0;     // busy slots: the ring positions ev_next - ev_in_flight .. ev_next - 1
     hipStream_t zero_stream = nullptr;            // re-zeroes the dispenser words of retired slots, off the callers' streams
@@ -529,6 +536,7 @@ int mirt_ctx_create(int device, MirtContext** out)
     c->slot_zeroing.assign(kEventPool, 0);
     c->slot_dirty.assign(kEventPool, 0);
     c->slot_zero_event.assign(kEventPool, 0);
+    c->slot_timed.assign(kEventPool, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->zero_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_sky, sizeof(MirtSkyState));
@@ -544,6 +552,7 @@ int mirt_ctx_create(int device, MirtContext** out)
     c->lds_per_block = prop.sharedMemPerBlock;            // 160 KiB on gfx950
     c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
     c->tuning = read_tuning();
+    c->timing = c->tuning.timing != 0;
     *out = c;
     return MIRT_OK;
 }
@@ -554,6 +563,7 @@ void mirt_ctx_destroy(MirtContext* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->zero_stream) (void)hipStreamSynchronize(c->zero_stream);
+    if (!c->untimed_streams.empty()) (void)hipDeviceSynchronize();      // launches without an event may still read the tables freed below
     (void)hipFree(c->d_spheres); (void)hipFree(c->d_mats); (void)hipFree(c->d_pmats); (void)hipFree(c->d_grid); (void)hipFree(c->d_shade); (void)hipFree(c->d_texels);
     (void)hipFree(c->d_sky); (void)hipFree(c->d_counters); (void)hipFree(c->d_work_counter); (void)hipFree(c->d_out); (void)hipFree(c->d_accum);
     for (hipEvent_t ev : c->ev_begin) (void)hipEventDestroy(ev);
@@ -763,7 +773,7 @@ static int fold_slot(MirtContext* c, size_t i)
     if (!c->slot_busy[i]) return MIRT_OK;
     HIP_TRY(hipEventSynchronize(c->ev_end[i]));
     float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+    if (c->slot_timed[i]) HIP_TRY(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));    // (untimed launches carry an end event only)
     c->ms_folded += ms;
     c->launches_folded += 1;
     c->last_ms = ms;
@@ -1065,7 +1075,20 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
 #endif
     if (count) HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(unsigned long long) * mirt::kNumCounters, stream));
-    HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
+    // Events.  A TIMED launch (mirt_ctx_set_timing, the default) carries a start and an end event for mirt_ctx_get_stats; they ride on
+    // the kernel dispatch itself (hipExtLaunchKernel), not as two record packets in the stream: per launch of the reference's own loop
+    // (parity mode, 2 spp, 800x600) 20.6 us with records, 17.9 with the events on the dispatch, 12.9 with none (profiles/r04_ring_ab.txt
+    // block 3).  An UNTIMED launch carries an end event only if something must learn that it has finished: its dispenser words have to
+    // be re-zeroed (dispensed units), or its counters will be read (counting launch).  The reference's interactive frames -- units
+    // dealt round-robin -- carry none.
+    const bool timed = c->timing;
+    const bool need_end = timed || count || a.static_units == 0u;
+    const bool ext_events = tune.ext_events && need_end;
+    if (timed && !ext_events) HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
+    struct EventsOnDispatch {                     // the launchers below read mirt::g_launch_events (launch_with_lds)
+        EventsOnDispatch(bool on, hipEvent_t b, hipEvent_t e) { if (on) { mirt::g_launch_events.begin = b; mirt::g_launch_events.end = e; } }
+        ~EventsOnDispatch() { mirt::g_launch_events = mirt::LaunchEvents{}; }
+    } events_on_dispatch(ext_events, timed ? c->ev_begin[ev] : nullptr, c->ev_end[ev]);
     // the opt-in fast-math build of the path-traced kernels; counting launches always run the exact build
     const bool fast = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
     const char* tf[2] = { "false", "true" };
@@ -1084,15 +1107,24 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     }
     // The kernel is enqueued: from here on the slot is in use, whatever happens below (a failure after this point must not hand the
     // slot -- its dispenser words no longer zero -- to the next launch: poison_slot).
-    c->slot_busy[ev] = 1;
-    c->ev_in_flight += 1;
     c->ev_next = (ev + 1) % c->ev_begin.size();
-    hipError_t he = hipEventRecord(c->ev_end[ev], stream);
+    hipError_t he = hipSuccess;
+    if (need_end) {
+        c->slot_busy[ev] = 1;
+        c->slot_timed[ev] = timed ? 1 : 0;
+        c->ev_in_flight += 1;
+        if (!ext_events) he = hipEventRecord(c->ev_end[ev], stream);
+    } else {                                      // nothing will ever wait for this launch through the context ...
+        c->launches_folded += 1;
+        c->last_ms = 0.0;
+        if (stream != c->stream && std::find(c->untimed_streams.begin(), c->untimed_streams.end(), stream) == c->untimed_streams.end())
+            c->untimed_streams.push_back(stream);   // ... except mirt_ctx_synchronize / _destroy, through its stream
+    }
     // Kernels that take units from the dispenser leave its words non-zero: retire_slots re-zeroes them before the slot's next use, on the
     // context's zero_stream -- never a memset node on the caller's stream, where it costs 3 us between kernels.  Launches whose units are
     // dealt round-robin (the reference's 2-spp frames, parity mode's lane = pixel) never touch the words.
     if (a.static_units == 0u) c->slot_dirty[ev] = 1;
-    if (he == hipSuccess && d_accum) {               // resolve/read must see these sums whatever stream they were added on
+    if (he == hipSuccess && d_accum && stream != c->stream) {   // resolve/read (on the context's stream) must see sums added on a caller stream
         he = hipEventRecord(c->ev_accum, stream);
         if (he == hipSuccess) c->accum_pending = true;
     }
@@ -1143,6 +1175,15 @@ int mirt_ctx_synchronize(MirtContext* c)
     for (size_t i = 0; i < c->ev_begin.size(); ++i) if (c->slot_busy[i]) HIP_TRY(hipEventSynchronize(c->ev_end[i]));
     HIP_TRY(hipStreamSynchronize(c->zero_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (hipStream_t st : c->untimed_streams) HIP_TRY(hipStreamSynchronize(st));      // launches that carried no event (mirt_ctx_set_timing(0))
+    c->untimed_streams.clear();
+    return MIRT_OK;
+}
+
+int mirt_ctx_set_timing(MirtContext* c, int enabled)
+{
+    if (!c) return fail(MIRT_ERR_NULL_POINTER, "ctx is null");
+    c->timing = enabled != 0;
     return MIRT_OK;
 }
 

@@ -197,6 +197,12 @@ struct DeinterleaveArgs {
     uint32_t        width, band_rows, tile_rows, n_parts;
 };
 
+// The event pair of the launch being issued (set by mirt_api.hip::launch_render around the launcher call, consumed by launch_with_lds):
+// non-null = the kernel is dispatched with hipExtLaunchKernel, which attaches start / stop timestamps to the dispatch ITSELF instead of
+// two separate event-record packets in the stream.
+struct LaunchEvents { hipEvent_t begin = nullptr, end = nullptr; };
+inline thread_local LaunchEvents g_launch_events;
+
 // launchers (mirt_kernels.hip).  That file is compiled twice: namespace exact_build (the default, bit-exact arithmetic;
 // everything below) and namespace fast_build (mirt_kernels_fast.hip: MIRT_FLAG_FAST_MATH, hardware transcendentals;
 // path-traced launchers and the host helpers only).

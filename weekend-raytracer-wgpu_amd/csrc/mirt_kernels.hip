@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <mutex>
 
+#include <hip/hip_ext.h>
 #include "mirt_kernels.h"
 #include "mirt_device_math.h"
 
@@ -1787,6 +1788,10 @@ static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a,
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes);
         if (e != hipSuccess) return e;
+    }
+    if (g_launch_events.end != nullptr) {
+        hipExtLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream, g_launch_events.begin, g_launch_events.end, 0u, a);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream, a);
     return hipGetLastError();
