@@ -338,6 +338,21 @@ def _soup(n_small, n_large, spread):
     return sph
 
 
+def _context_with_dispensed_units():
+    """A context whose lane-per-pixel launches take their units from the dispenser (rounds 2-3's schedule; round 4 runs one unit per
+    wave there): the tuning knobs are read once, in mirt_ctx_create."""
+    import os
+    saved = os.environ.get("MIRT_STATIC_UNITS")
+    os.environ["MIRT_STATIC_UNITS"] = "0"
+    try:
+        return m.Context(0)
+    finally:
+        if saved is None:
+            del os.environ["MIRT_STATIC_UNITS"]
+        else:
+            os.environ["MIRT_STATIC_UNITS"] = saved
+
+
 def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
     """A launch takes its work units from dispenser words that belong to its slot of the event ring and start at zero (no memset
     node in front of the kernel); a slot's words are re-zeroed behind the kernel that used them, on the context's own stream, and
@@ -346,7 +361,7 @@ def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
     import torch
     w, h = 800, 400                  # 20 000 units of 16 pixels: more than the waves of a launch, so most units come from the dispenser
     sd = scene_data("three_spheres", w, h)
-    ctx = m.Context(0)
+    ctx = _context_with_dispensed_units()
     ctx.set_scene(sd)
     out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -372,7 +387,7 @@ def test_the_event_ring_wraps_with_launches_on_two_streams(oracle):
     import torch
     w, h = 640, 360
     sd = scene_data("three_spheres", w, h)
-    ctx = m.Context(0)
+    ctx = _context_with_dispensed_units()
     ctx.set_scene(sd)
     pa = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3)                                   # strip kernel, lane = pixel, dispensed units
     pb = m.make_params(w, h, 32, mode=m.MIRT_MODE_PT, seed=4, flags=m.MIRT_FLAG_KERNEL_POOL)   # pooled kernel
@@ -414,10 +429,10 @@ def test_untimed_launches_render_the_same_frames_and_report_no_kernel_time(oracl
     import torch
     w, h = 640, 360
     sd = scene_data("three_spheres", w, h)
-    ctx = m.Context(0)
+    ctx = _context_with_dispensed_units()
     ctx.set_scene(sd)
     ctx.set_timing(False)
-    p2 = m.make_params(w, h, 2, mode=m.MIRT_MODE_PT)                                           # units dealt round-robin: no event at all
+    p2 = m.make_params(w, h, 2, mode=m.MIRT_MODE_PT)                                           # one unit per wave: no event at all (default context below)
     p8 = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3)                                   # dispensed units: an end event only
     pp = m.make_params(w, h, 32, mode=m.MIRT_MODE_PT, seed=4, flags=m.MIRT_FLAG_KERNEL_POOL)   # pooled kernel, dispensed
     want2, want8, wantp = oracle.render(sd, p2), oracle.render(sd, p8), oracle.render(sd, pp)
@@ -443,11 +458,16 @@ def test_untimed_launches_render_the_same_frames_and_report_no_kernel_time(oracl
     assert st["launches"] == 200 and st["kernel_ms_total"] == 0.0 and st["kernel_ms"] == 0.0
     c2.fill_(0xAB)
     torch.cuda.synchronize()
+    plain = m.Context(0)                                   # the default schedule: a 2-spp frame runs one unit per wave, no dispenser
+    plain.set_scene(sd)
+    plain.set_timing(False)
     for _ in range(150):                                   # the reference's interactive frame: no event, no slot bookkeeping
-        ctx.render_device(p2, c2.data_ptr(), c2.numel(), s1.cuda_stream)
-    ctx.synchronize()                                      # no torch synchronisation: the context waits for the caller's stream itself
+        plain.render_device(p2, c2.data_ptr(), c2.numel(), s1.cuda_stream)
+    plain.synchronize()                                    # no torch synchronisation: the context waits for the caller's stream itself
     assert np.array_equal(c2.cpu().numpy(), want2)
-    assert ctx.stats()["launches"] == 150
+    st = plain.stats()
+    assert st["launches"] == 150 and st["kernel_ms_total"] == 0.0
+    plain.close()
     # counting launches keep their end event (their counters are read afterwards), timing on again reports times again
     pc = m.make_params(w, h, 8, mode=m.MIRT_MODE_PT, seed=3, flags=m.MIRT_FLAG_COUNT_WORK)
     assert np.array_equal(ctx.render(pc), want8)

@@ -687,18 +687,18 @@ def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
 
 
 def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
-    """mirt_kernels.h kPoolMinSpp*: several shading routines -> pool from 28 spp; one routine -> lane-per-pixel strip kernel below
-    600 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
+    """mirt_kernels.h kPoolMinSpp*: several shading routines -> pool from 32 spp; one routine -> lane-per-pixel strip kernel below
+    800 spp (on frames large enough to feed every CU), pool from there; many-sphere scenes -> grid pool from 16 spp.  Every
     choice renders the same image as the forced alternatives (checked throughout this file); here: the names."""
     def kernel(scene, w, h, spp):
         gpu_ctx.set_scene(scene_data(scene, w, h))
         gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8))
         return gpu_ctx.last_kernel()
-    assert kernel("three_spheres", 640, 360, 24) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("three_spheres", 640, 360, 28).startswith("render_pt_pool_kernel<256,112,6,")
+    assert kernel("three_spheres", 640, 360, 28) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("three_spheres", 640, 360, 32).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 640, 360, 100) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 592) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 600).startswith("render_pt_pool_kernel<256,112,6,")
+    assert kernel("single_sphere", 640, 360, 792) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("single_sphere", 640, 360, 800).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 64, 36, 100) == "render_pt_strip_kernel<false,false,false,false>"      # tiny frame: lanes on samples
     assert kernel("rtiow_final", 640, 360, 12) == "render_pt_strip_kernel<false,false,true,true>"
     assert kernel("rtiow_final", 640, 360, 16).startswith("render_pt_pool_kernel<1024,")

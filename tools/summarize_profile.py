@@ -53,7 +53,10 @@ def main() -> int:
     kernel_id = bench["roofline"]["kernel"]
     needle = rocprof_spelling(kernel_id)
     (dst / f"{tag}_bench.json").write_text(bench_line + "\n")
-    stats = glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True)
+    import os
+    # gpurun MERGES a visit's files into gpurun_out/: a workload profiled twice has both visits' files side by side -- the NEWEST one per
+    # pass is the build being summarised
+    stats = sorted(glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if not stats:
         print("no kernel_stats.csv under", src)
         return 1
@@ -68,7 +71,12 @@ def main() -> int:
         return 1
     counters: dict[str, list[float]] = collections.defaultdict(list)
     meta = {}
-    for f in sorted(glob.glob(str(src / "pmc*" / "**" / "*_counter_collection.csv"), recursive=True)):
+    newest: dict[str, str] = {}
+    for f in glob.glob(str(src / "pmc*" / "**" / "*_counter_collection.csv"), recursive=True):
+        pass_dir = Path(f).relative_to(src).parts[0]
+        if pass_dir not in newest or os.path.getmtime(f) > os.path.getmtime(newest[pass_dir]):
+            newest[pass_dir] = f
+    for f in sorted(newest.values()):
         for row in csv.DictReader(open(f)):
             if needle in row["Kernel_Name"]:
                 counters[row["Counter_Name"]].append(float(row["Counter_Value"]))

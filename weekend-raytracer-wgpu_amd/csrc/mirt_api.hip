@@ -242,6 +242,7 @@ struct Tuning {
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
+    int      static_grid = -1;        // MIRT_STATIC_GRID=k (A/B runs): launches with one unit per wave run k x the resident blocks instead, units dealt round-robin
     int      timing = -1;             // MIRT_TIMING=0/1: the context's initial mirt_ctx_set_timing state (A/B runs; default 1)
     bool     ext_events = true;       // MIRT_EXT_EVENTS=0: the event pair as two records in the stream instead of riding on the kernel dispatch (A/B runs)
 };
@@ -263,6 +264,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
+    if (const char* e = std::getenv("MIRT_STATIC_GRID")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) t.static_grid = v; }
     if (const char* e = std::getenv("MIRT_TIMING")) t.timing = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_EXT_EVENTS")) t.ext_events = e[0] != '0';
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }
@@ -1015,24 +1017,23 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // the same at 3840x2160 3.20 / 2.96 / 2.89, at 800x600 0.71 / 0.41 / 0.33 -- and one more for many-sphere scenes (RTIOW 8 spp:
         // 1.54 / 1.40).  The samples must divide evenly; never with the reference's per-frame stream (sequentially dependent samples).
         if (pt && !frame_stream && tune.px_groups != 0) {
-            // (round 4, profiles/r04_lowspp_ab.txt: three spheres at 12 spp, two groups of 6: 0.486 ms against 0.529 for one group of 12 -> shares of >= 6)
-            const uint32_t min_share = use_grid ? 4u : 6u;
-            while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= min_share)
+            // (round 4, one unit per wave, profiles/r04_lowspp_ab.txt block 4: two groups from shares of 4 -- three spheres 8 spp 0.337 ms against
+            //  0.359, main.rs scene 0.434 / 0.459 --, four groups from shares of 6: 16 spp 0.610 with two groups, 0.617 with four; 24 spp 0.884 / 0.881)
+            const uint32_t min_share[2] = { 4u, use_grid ? 4u : 6u };
+            while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= min_share[a.px_groups_log2])
                 a.px_groups_log2 += 1u;
             if (tune.px_groups > 0 && p->spp % (1u << (tune.px_groups - 1)) == 0u) a.px_groups_log2 = (uint32_t)tune.px_groups - 1u;
         }
         a.n_units = (uint32_t)((npix + (64u >> a.px_groups_log2) - 1u) / (64u >> a.px_groups_log2));
-        // units dealt round-robin instead of dispensed: path-traced mode below 4 spp (measured crossover; 8 before the eight-word dispenser); parity mode
-        // always -- its lane = pixel units are a few dozen sphere tests each, and one dispenser atomic per unit (14 ns, serialised on
-        // its address) was the whole kernel time: 7 500 units of an 800x600 frame at 2 spp 94 us whatever the work
-        a.static_units = (!pt || p->spp < 4u) ? 1u : 0u;  // (three spheres 1080p: 2 spp 0.132 ms dealt / 0.169 dispensed, 4 spp 0.244 / 0.234)
-        // 4 spp in flat scenes: 32-pixel units with two sample groups of 2, dealt round-robin (three spheres 0.219 ms against 0.227 dispensed
-        // 64-pixel units and 0.240 dealt ones; main.rs scene 0.297 / 0.300; profiles/r04_lowspp_ab.txt)
-        if (pt && !frame_stream && !use_grid && p->spp == 4u && tune.px_groups < 0 && tune.static_units < 0) {
-            a.static_units = 1u;
-            a.px_groups_log2 = 1u;
-            a.n_units = (uint32_t)((npix + 31u) / 32u);
-        }
+        // ONE UNIT PER WAVE instead of units dispensed to a persistent grid (a.static_units; round 4): the launch has as many waves as units, and
+        // the hardware's workgroup dispatcher -- which starts a block wherever a CU has room -- is the load balancer: no dispenser atomic
+        // (one returning device-scope atomic per unit, 14 ns each on one address, was the whole kernel time of a 2-spp frame), and none of
+        // the imbalance of dealing units round-robin to resident waves (rounds 2-3: a wave's four units are a quarter of its life each).
+        // Measured against both (profiles/r04_lowspp_ab.txt block 3; 1080p, three spheres): 1 / 2 / 4 / 8 / 16 / 24 spp -14 / -16 / -13 / -4 / -2 /
+        // +-0 %; main.rs scene 2 spp -20 %; config 2 -1.6 %; parity mode's lane = pixel 2 spp (1080p) -11 %, 32 spp -21 %.  Every block stages
+        // the scene itself, which is why many-sphere scenes (a 25 KB grid blob per block) keep the dispenser from 4 spp on (RTIOW: 2 spp -21 %,
+        // 4 / 8 / 12 spp +7 / +8 / +7 %).
+        a.static_units = (!pt || !use_grid || p->spp < 4u) ? 1u : 0u;
         if (tune.static_units >= 0) a.static_units = (uint32_t)tune.static_units;
     }
 
@@ -1058,7 +1059,11 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
                                      : kx::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes);
         if (per_cu > 8u) per_cu = 8u;                                 // 2048 threads per CU / 256
         const uint32_t resident = (uint32_t)c->cu_count * per_cu;
-        if (blocks > resident) blocks = resident;
+        // ... unless the launch runs one unit per wave (a.static_units): then the grid is the units (MIRT_STATIC_GRID=k, A/B runs: k x the
+        // resident blocks with the units dealt round-robin, rounds 2-3's schedule at k = 1)
+        uint32_t cap = resident;
+        if (a.static_units != 0u) cap = tune.static_grid > 0 ? resident * (uint32_t)tune.static_grid : blocks;
+        if (blocks > cap) blocks = cap;
     }
     if (blocks == 0) blocks = 1;
 

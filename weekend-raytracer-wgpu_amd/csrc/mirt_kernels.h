@@ -133,8 +133,11 @@ constexpr uint32_t kGridPoolSlotChoices[4] = { MIRT_GRID_SLOTS };   // the large
 //     8.48 ms at 100 / 200 / 400 / 600 / 800 / 1000 spp, pool 1.81 / 2.42 / 3.85 / 5.17 / 6.52 / 7.96                                           -> 600
 //   many-sphere scenes (grid build, RTIOW): round 2: strip 2.09 / 4.11 / 7.69 ms at 8 / 16 / 32 spp, pool 2.31 / 3.14 / 4.66 -> 16;
 //     round 3: strip 1.54 / 2.19 / 2.70 ms at 8 / 12 / 16 spp, pool 1.99 / 2.28 / 2.61                                                          -> 16
-constexpr uint32_t kPoolMinSpp           = 28;
-constexpr uint32_t kPoolMinSppOneRoutine = 600;
+//   round 4 (lane-per-pixel launches run one unit per wave; profiles/r04_lowspp_ab.txt block 5): several routines: strip 0.96 / 1.10 / 1.27 /
+//     1.52 ms at 24 / 28 / 32 / 40 spp, pool 1.01 / 1.12 / 1.20 / 1.39 (main.rs scene 1.26 / 1.66 against 1.32 / 1.56 at 24 / 32)             -> 32
+//     ONE routine: strip 3.36 / 4.81 / 6.49 / 8.11 ms at 400 / 600 / 800 / 1000 spp, pool 3.80 / 5.25 / 6.52 / 7.93                           -> 800
+constexpr uint32_t kPoolMinSpp           = 32;
+constexpr uint32_t kPoolMinSppOneRoutine = 800;
 constexpr uint32_t kPoolMinSppGrid       = 16;
 
 enum CounterSlot : uint32_t {
