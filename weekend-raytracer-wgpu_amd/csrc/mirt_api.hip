@@ -238,7 +238,7 @@ struct Tuning {
     double   grid_big = 0.0;          // MIRT_GRID_BIG: spheres above this many median radii stay outside the grid
     int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
     int      spread_units = -1;       // MIRT_SPREAD_UNITS=0: strip-type launches use one dispenser word (A/B runs)
-    int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed / dealt round-robin (A/B runs)
+    int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed to a persistent grid / one unit per wave (A/B runs, tests)
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
@@ -264,7 +264,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
-    if (const char* e = std::getenv("MIRT_STATIC_GRID")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) t.static_grid = v; }
+    if (const char* e = std::getenv("MIRT_STATIC_GRID")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) t.static_grid = v; }
     if (const char* e = std::getenv("MIRT_TIMING")) t.timing = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_EXT_EVENTS")) t.ext_events = e[0] != '0';
     if (const char* e = std::getenv("MIRT_GRID_BIG")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) t.grid_big = v; }

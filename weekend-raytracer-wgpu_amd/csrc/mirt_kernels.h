@@ -180,7 +180,7 @@ struct RenderArgs {
     uint32_t first_dispensed;              // the dispenser's words start at ZERO (pre-zeroed per launch slot, no memset node in front of the kernel):
                                            // units below this one -- one per launched wave -- are taken by wave index (first_unit)
     uint32_t disp_taken[8];                // eight-word dispenser: how many of word x's units (u = 8 k + x) those are
-    uint32_t static_units;                 // lane-per-pixel strip kernel: units dealt round-robin instead of dispensed
+    uint32_t static_units;                 // lane-per-pixel kernels: no dispenser -- unit = wave index (+ the grid's waves, if the host launched fewer waves than units)
     uint32_t spread_units;                 // strip-type kernels: units from eight dispenser words (unit u <-> word u mod 8; next_unit_any)
     uint32_t px_groups_log2;               // lane-per-pixel strip kernel: a unit is 64 >> g pixels, their samples dealt to 1 << g groups of lanes
     // pool kernel, guided self-scheduling: level l = strips of (kStripPixels >> l) pixels; it starts at unit

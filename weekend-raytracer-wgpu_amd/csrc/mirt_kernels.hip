@@ -1510,9 +1510,10 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
     Work<COUNT> work;
     work.clear();
 
-    // BY_PIXEL units are small (64 pixels x a few samples).  With very few samples they are dealt round-robin to
-    // the waves of the grid (A.static_units): one dispenser atomic per unit serialises on its address (measured:
-    // 14 ns each, 0.47 ms for the 32 400 units of a 1080p frame whatever the work) and the units are alike.
+    // BY_PIXEL units are small (16-64 pixels x a few samples).  With A.static_units they take no dispenser: a wave's unit is its index,
+    // and the host launches as many waves as units (round 4: the hardware's workgroup dispatcher is the load balancer; a grid of fewer
+    // waves -- rounds 2-3, MIRT_STATIC_GRID -- deals the units round-robin).  One dispenser atomic per unit serialises on its address
+    // (measured: 14 ns each, 0.47 ms for the 32 400 units of a 1080p frame whatever the work).
     const uint32_t grid_waves = gridDim.x * (kBlockThreads / 64u);
     // (Dispensing these units in batches -- a static first batch per wave, then guided batches of (units left) / (waves) per atomic -- was
     //  measured: 16 ... 110 % SLOWER than one unit per atomic at every unit size; eight dispenser words instead of one: 1 ... 9 % slower.)
