@@ -39,9 +39,9 @@ def test_layer_scene_vs_oracle(gpu_ctx, oracle, w, h, spp):
     assert_images_equal(_render(gpu_ctx, sd, p), oracle.render(sd, p), f"{w}x{h} spp{spp}")
 
 
-@pytest.mark.parametrize("w,h,spp", [(160, 120, 2), (333, 77, 21), (200, 150, 40), (17, 1, 2), (800, 600, 2)])
+@pytest.mark.parametrize("w,h,spp", [(160, 120, 2), (333, 77, 21), (200, 150, 40), (17, 1, 2), (800, 600, 2), (192, 108, 100), (96, 54, 1000)])
 def test_lane_per_pixel_and_lane_per_sample_schedules_agree(gpu_ctx, oracle, w, h, spp):
-    """Below 64 samples per pixel parity mode runs lane = pixel (every lane walks the reference's sample loop for its own
+    """Parity mode runs lane = pixel at every sample count (round 3: below 64; every lane walks the reference's sample loop for its own
     pixel, layer.rs:320-378); MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule.  Same image, same work counters,
     and the kernel names say which one ran."""
     sd = layer_scene_data(w, h)

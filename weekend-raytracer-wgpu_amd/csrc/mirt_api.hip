@@ -1004,8 +1004,11 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     bool by_pixel = pt && !pool && !count && (p->spp < mirt::kByPixelMaxSpp || (c->n_shading_routines <= 1 && npix >= 64ull * 4u * c->cu_count));
     if (tune.by_pixel >= 0) by_pixel = pt && !pool && !count && tune.by_pixel == 1;
     if (frame_stream) by_pixel = true;                    // also for counting launches (flat scan) and any spp
-    // parity mode at the reference's operating point (2 samples per pixel, mod.rs:605-613): lane = pixel as well, counting or not
-    if (!pt) by_pixel = (p->flags & MIRT_FLAG_KERNEL_STRIP) ? false : (tune.by_pixel >= 0 ? tune.by_pixel == 1 : p->spp < mirt::kByPixelMaxSpp);
+    // parity mode: lane = pixel at EVERY sample count, counting or not (round 3: below 64 spp).  The reference's loop returns at the first
+    // terminating sample (layer.rs:320-378), which a lane that walks its own pixel's samples does too, while lane = sample computes 64
+    // samples of a pixel to find it: with one unit per wave 1080p x 64 / 100 / 1000 spp take 0.29 / 0.34 / 1.89 ms against 1.14 / 1.17 /
+    // 2.08 (profiles/r04_lowspp_ab.txt block 7).  MIRT_FLAG_KERNEL_STRIP still forces lane = sample (same image, same work counters).
+    if (!pt) by_pixel = (p->flags & MIRT_FLAG_KERNEL_STRIP) ? false : (tune.by_pixel >= 0 ? tune.by_pixel == 1 : true);
     a.static_units = 0;
     a.px_groups_log2 = 0;
     if (by_pixel) {
