@@ -1093,23 +1093,20 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     const bool need_end = timed || count || a.static_units == 0u;
     const bool ext_events = tune.ext_events && need_end;
     if (timed && !ext_events) HIP_TRY(hipEventRecord(c->ev_begin[ev], stream));
-    struct EventsOnDispatch {                     // the launchers below read mirt::g_launch_events (launch_with_lds)
-        EventsOnDispatch(bool on, hipEvent_t b, hipEvent_t e) { if (on) { mirt::g_launch_events.begin = b; mirt::g_launch_events.end = e; } }
-        ~EventsOnDispatch() { mirt::g_launch_events = mirt::LaunchEvents{}; }
-    } events_on_dispatch(ext_events, timed ? c->ev_begin[ev] : nullptr, c->ev_end[ev]);
+    const mirt::LaunchOn on = ext_events ? mirt::LaunchOn(stream, timed ? c->ev_begin[ev] : nullptr, c->ev_end[ev]) : mirt::LaunchOn(stream);
     // the opt-in fast-math build of the path-traced kernels; counting launches always run the exact build
     const bool fast = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
     const char* tf[2] = { "false", "true" };
     char kname[112] = "";
     if (p->mode == MIRT_MODE_PARITY) {
-        HIP_TRY(kx::launch_parity(a, blocks, count, by_pixel, stream));
+        HIP_TRY(kx::launch_parity(a, blocks, count, by_pixel, on));
         snprintf(c->last_kernel, sizeof c->last_kernel, "render_parity_kernel<%s,%s>", tf[count], tf[by_pixel]);
     } else if (pool) {
-        HIP_TRY(fast ? kf::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream) : kx::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, stream));
+        HIP_TRY(fast ? kf::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, on) : kx::launch_pt_pool(a, blocks, pool_cfg, count, pool_nq, on));
         kx::pool_kernel_name(a, pool_cfg, count, pool_nq, kname, sizeof kname);
         snprintf(c->last_kernel, sizeof c->last_kernel, "%s%s", fast ? "fast_build::" : "", kname);
     } else {
-        HIP_TRY(fast ? kf::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream) : kx::launch_pt_strip(a, blocks, count, use_grid, by_pixel, stream));
+        HIP_TRY(fast ? kf::launch_pt_strip(a, blocks, count, use_grid, by_pixel, on) : kx::launch_pt_strip(a, blocks, count, use_grid, by_pixel, on));
         snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
                  tf[use_grid], tf[by_pixel]);
     }

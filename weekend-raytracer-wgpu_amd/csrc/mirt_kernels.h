@@ -200,31 +200,33 @@ struct DeinterleaveArgs {
     uint32_t        width, band_rows, tile_rows, n_parts;
 };
 
-// The event pair of the launch being issued (set by mirt_api.hip::launch_render around the launcher call, consumed by launch_with_lds):
-// non-null = the kernel is dispatched with hipExtLaunchKernel, which attaches start / stop timestamps to the dispatch ITSELF instead of
-// two separate event-record packets in the stream.
-struct LaunchEvents { hipEvent_t begin = nullptr, end = nullptr; };
-inline thread_local LaunchEvents g_launch_events;
+// Where a render kernel is dispatched: the stream, and optionally the event pair of the launch.  Non-null events ride on the kernel
+// dispatch itself (hipExtLaunchKernel attaches start / stop timestamps to the dispatch) instead of two event-record packets in the stream.
+struct LaunchOn {
+    hipStream_t stream = nullptr;
+    hipEvent_t  begin = nullptr, end = nullptr;
+    LaunchOn(hipStream_t s = nullptr, hipEvent_t b = nullptr, hipEvent_t e = nullptr) : stream(s), begin(b), end(e) {}
+};
 
 // launchers (mirt_kernels.hip).  That file is compiled twice: namespace exact_build (the default, bit-exact arithmetic;
 // everything below) and namespace fast_build (mirt_kernels_fast.hip: MIRT_FLAG_FAST_MATH, hardware transcendentals;
 // path-traced launchers and the host helpers only).
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 namespace fast_build {
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream);
 uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes);
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, LaunchOn stream);
 }
 namespace exact_build {
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, hipStream_t stream);
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream);
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, LaunchOn stream);
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream);
 // blocks of the kernel such a launch runs that are resident per CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes);
 uint32_t   parity_blocks_per_cu(bool count, bool by_pixel, uint32_t lds_bytes);
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
 PoolConfig pool_config_grid(size_t lds_for_pools);   // grid build: slots by the LDS left beside scene + grid (slots = 0: none fits)
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream);
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, LaunchOn stream);
 // template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID>
 void       pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len);
 uint32_t pool_scatter_queues(uint32_t n_routines, bool count);

@@ -1783,18 +1783,18 @@ size_t scene_lds_bytes_grid(uint32_t n_spheres, bool hosek)      // GRID build: 
 
 
 template <typename K>
-static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a, hipStream_t stream)
+static hipError_t launch_with_lds(K kernel, dim3 g, dim3 b, const RenderArgs& a, LaunchOn stream)
 {
     if (a.lds_bytes > 48u * 1024u) {        // more than the default dynamic-LDS window: ask for it
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    if (g_launch_events.end != nullptr) {
-        hipExtLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream, g_launch_events.begin, g_launch_events.end, 0u, a);
+    if (stream.end != nullptr) {                   // the launch's event pair rides on the dispatch
+        hipExtLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream.stream, stream.begin, stream.end, 0u, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream, a);
+    hipLaunchKernelGGL(kernel, g, b, a.lds_bytes, stream.stream, a);
     return hipGetLastError();
 }
 
@@ -1806,7 +1806,7 @@ static ParityKernel parity_kernel(bool count, bool by_pixel)
     return count ? render_parity_kernel<true, false> : render_parity_kernel<false, false>;
 }
 
-hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, hipStream_t stream)
+hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, LaunchOn stream)
 {
     return launch_with_lds(parity_kernel(count, by_pixel), dim3(grid_blocks), dim3(kBlockThreads), a, stream);
 }
@@ -1833,7 +1833,7 @@ static StripKernel strip_kernel(bool count, bool hosek, bool use_grid, bool by_p
     return hosek ? render_pt_strip_kernel<false, true, false> : render_pt_strip_kernel<false, false, false>;
 }
 
-hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, hipStream_t stream)
+hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream)
 {
     const StripKernel k = strip_kernel(count, (a.flags & MIRT_FLAG_SKY_HOSEK) != 0, use_grid, by_pixel);
     if (!k) return hipErrorInvalidValue;
@@ -1880,7 +1880,7 @@ uint32_t parity_blocks_per_cu(bool count, bool by_pixel, uint32_t lds_bytes)
 // tile geometry -- a scene with fewer shading routines than queues would carry empty queues through every pick and push
 // (two routines, config 4: -1.2 %)
 template <uint32_t T, uint32_t SL, uint32_t MW = 1, bool FEW = false>
-static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
+static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, LaunchOn stream)
 {
     const dim3 g(grid_blocks), b(T);
 #ifdef MIRT_FAST_MATH
@@ -1905,7 +1905,7 @@ static hipError_t launch_pool_cfg(const RenderArgs& a, uint32_t grid_blocks, boo
 
 // the tile build (MIRT_FLAG_TEXEL_TILES): fewer slots, a texel window per wave
 template <uint32_t T, uint32_t SL, uint32_t MW>
-static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
+static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, LaunchOn stream)
 {
     const dim3 g(grid_blocks), b(T);
 #ifdef MIRT_FAST_MATH
@@ -1928,7 +1928,7 @@ static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bo
 
 // grid build of the default pool geometry: LDS (scene + grid + pools) bounds it to a few blocks per CU, so the
 // register budget is not the limit
-static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, hipStream_t stream)
+static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, LaunchOn stream)
 {
     const dim3 g(grid_blocks), b(kGridPoolThreads);
     (void)nq;                                   // grid builds have ONE scatter queue (per-lane material switch)
@@ -2020,7 +2020,7 @@ uint32_t pool_scatter_queues(uint32_t n_routines, bool count)
     return n_routines < 1 ? 1u : n_routines;
 }
 
-hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, hipStream_t stream)
+hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, LaunchOn stream)
 {
     const bool hosek = (a.flags & MIRT_FLAG_SKY_HOSEK) != 0;
     if (a.grid) return launch_pool_grid(a, grid_blocks, count, hosek, nq, stream);     // host: default geometry only
