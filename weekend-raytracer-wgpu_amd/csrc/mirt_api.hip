@@ -242,6 +242,7 @@ struct Tuning {
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
+    uint32_t static_block = 0;        // MIRT_STATIC_BLOCK=64/128/256 (A/B runs): threads per block of the launches that run one unit per wave
     int      static_grid = -1;        // MIRT_STATIC_GRID=k (A/B runs): launches with one unit per wave run k x the resident blocks instead, units dealt round-robin
     int      timing = -1;             // MIRT_TIMING=0/1: the context's initial mirt_ctx_set_timing state (A/B runs; default 1)
     bool     ext_events = true;       // MIRT_EXT_EVENTS=0: the event pair as two records in the stream instead of riding on the kernel dispatch (A/B runs)
@@ -264,6 +265,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
+    if (const char* e = std::getenv("MIRT_STATIC_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) t.static_block = (uint32_t)v; }
     if (const char* e = std::getenv("MIRT_STATIC_GRID")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) t.static_grid = v; }
     if (const char* e = std::getenv("MIRT_TIMING")) t.timing = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_EXT_EVENTS")) t.ext_events = e[0] != '0';
@@ -1052,7 +1054,13 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         const uint32_t need = (a.n_units + units_per_block - 1) / units_per_block;
         if (blocks > need) blocks = need;
     } else {
-        const uint32_t waves_per_block = mirt::kBlockThreads / 64;
+        // One unit per wave in a flat scene: one WAVE per block, too -- a block leaves when its slowest wave is done, and the scene a block
+        // stages is a few hundred bytes (1080p, three spheres 2 / 4 / 8 / 16 spp -1.6 / -2.2 / -1.5 / -1.3 %, config 2 -1.9 %, parity mode at
+        // 1000 spp nominal -15 %; profiles/r04_lowspp_ab.txt block 8).  Many-sphere scenes stage a 25 KB grid blob per block: 256 threads
+        // (RTIOW 2 spp with 64-thread blocks: 2.4 x the time).  MIRT_STATIC_BLOCK=64/128/256 for A/B runs.
+        a.launch_threads = 0u;
+        if (a.static_units != 0u && tune.static_grid <= 0) a.launch_threads = tune.static_block ? tune.static_block : (use_grid ? 0u : 64u);
+        const uint32_t waves_per_block = (a.launch_threads ? a.launch_threads : mirt::kBlockThreads) / 64;
         blocks = (a.n_units + waves_per_block - 1) / waves_per_block;
         // a persistent grid of exactly the blocks that are resident at once: registers and LDS decide (4-8 per CU for these
         // kernels).  A block beyond that would hold its first unit until the dispenser has run dry and run it alone at the end.
@@ -1071,7 +1079,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (blocks == 0) blocks = 1;
 
     // the dispenser continues after the units the waves take by their own index (first_unit() in the kernels)
-    const uint32_t launched_waves = blocks * ((pool ? pcu.threads : mirt::kBlockThreads) / 64u);
+    const uint32_t launched_waves = blocks * ((pool ? pcu.threads : (a.launch_threads ? a.launch_threads : mirt::kBlockThreads)) / 64u);
     // kernels with dispensed units take them from eight dispenser words (mirt_kernels.hip: next_unit_any): the strip-type kernels
     // (path-traced strip kernel, both schedules; parity kernel) always.
     // The pooled kernel's strips last long at high sample counts (config 3: 9 atomics per microsecond); below 128 spp they do not

@@ -190,6 +190,7 @@ struct RenderArgs {
     uint32_t lvl_pix[6];
     uint32_t queue_routine[5];             // pool kernel: scatter queue q runs routine queue_routine[q] = min(GpuMaterial.id, 4)
     uint32_t lds_bytes;
+    uint32_t launch_threads;               // strip-type kernels: threads per block of THIS launch (0: kBlockThreads)
     float    sph3[12];                     // scenes of exactly three spheres: their {centre, r^2} records as kernel arguments (scalar loads)
 };
 

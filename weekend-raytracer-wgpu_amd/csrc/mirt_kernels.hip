@@ -1808,7 +1808,7 @@ static ParityKernel parity_kernel(bool count, bool by_pixel)
 
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, LaunchOn stream)
 {
-    return launch_with_lds(parity_kernel(count, by_pixel), dim3(grid_blocks), dim3(kBlockThreads), a, stream);
+    return launch_with_lds(parity_kernel(count, by_pixel), dim3(grid_blocks), dim3(a.launch_threads ? a.launch_threads : kBlockThreads), a, stream);
 }
 
 #endif
@@ -1837,7 +1837,7 @@ hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count
 {
     const StripKernel k = strip_kernel(count, (a.flags & MIRT_FLAG_SKY_HOSEK) != 0, use_grid, by_pixel);
     if (!k) return hipErrorInvalidValue;
-    return launch_with_lds(k, dim3(grid_blocks), dim3(kBlockThreads), a, stream);
+    return launch_with_lds(k, dim3(grid_blocks), dim3(a.launch_threads ? a.launch_threads : kBlockThreads), a, stream);
 }
 
 // Blocks of a kernel that are resident per CU at once (registers and LDS decide: the strip kernels use 59-106 VGPRs).  The
