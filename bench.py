@@ -144,6 +144,8 @@ def kernel_schedule(name: str) -> str:
     targs = name[name.index("<") + 1:name.rindex(">")].split(",")
     if fam == "render_pt_strip_kernel":
         return "strip/pixel" if targs[3] == "true" else "strip/sample"
+    if fam == "render_pt_stream_kernel":                # lane = pixel, a lane starts its next sample without waiting for the wave
+        return "strip/pixel-stream"
     if fam == "render_parity_kernel":
         return "parity/pixel" if len(targs) > 1 and targs[1] == "true" else "parity/sample"
     return "pool" if fam.startswith("render_pt_pool") else fam
@@ -918,7 +920,7 @@ def main(argv=None) -> int:
             result["fast_math"] = fast_math_line(m, torch, ctx, base, frame.frame, total_samples, flops)
             if args.config == "4":
                 result["texel_tiles"] = texel_tiles_line(m, torch, ctx, base, frame.frame, total_samples)
-            if args.config == "2":
+            if args.config == "2" and not args.no_cpu_baseline:   # (not in the profiler passes: since round 4 it runs the timed kernel itself)
                 result["steady_state"] = steady_state_line(m, torch, ctx, base, w, h)
         if not multi and cfg["mode"] == "parity":
             result["parity_schedules"] = parity_schedules_line(m, torch, ctx, base, w, h)

@@ -141,6 +141,7 @@ def test_algorithmic_bytes_count_only_what_a_launch_reads():
 def test_kernel_schedule_names():
     assert bench.kernel_schedule("render_pt_strip_kernel<false,false,false,true>") == "strip/pixel"
     assert bench.kernel_schedule("render_pt_strip_kernel<true,false,false,false>") == "strip/sample"
+    assert bench.kernel_schedule("render_pt_stream_kernel<false>") == "strip/pixel-stream" and not bench.kernel_uses_grid("render_pt_stream_kernel<false>")
     assert bench.kernel_schedule("render_pt_pool_kernel<256,112,6,false,false,3,false>") == bench.kernel_schedule("render_pt_pool_kernel<256,112,1,true,false,5,false>") == "pool"
     assert bench.kernel_schedule("render_parity_kernel<false,true>") == "parity/pixel" != bench.kernel_schedule("render_parity_kernel<true,false>")
 

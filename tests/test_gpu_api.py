@@ -389,7 +389,7 @@ def test_dispenser_slots_are_clean_across_the_event_pool(oracle):
             if i % 37 == 0 or i == 149:
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy(), want), (spp, i)
-        assert ctx.stats()["launches"] == 150 and ctx.last_kernel().startswith("render_pt_pool" if flags else "render_pt_strip")
+        assert ctx.stats()["launches"] == 150 and ctx.last_kernel().startswith("render_pt_pool" if flags else "render_pt_str")
     ctx.close()
 
 

@@ -54,7 +54,7 @@ def test_config1_plumbing_and_config3_parity_mode(gpu_ctx, oracle):
 
 
 FULL_SIZE = [  # name, scene, width, height, spp exactly as BASELINE.json names them, chunk of the accumulation, kernel expected
-    ("config2", "single_sphere", 1920, 1080, 100, 25, "render_pt_strip_kernel<false,false,false,true>"),
+    ("config2", "single_sphere", 1920, 1080, 100, 25, "render_pt_stream_kernel<false>"),
     ("config3", "three_spheres", 1920, 1080, 1000, 250, "render_pt_pool_kernel<256,"),
     ("config4", "earth", 1920, 1080, 1000, 125, "render_pt_pool_kernel<256,"),
     ("config5", "rtiow_final", 3840, 2160, 4000, 500, "render_pt_pool_kernel<1024,"),

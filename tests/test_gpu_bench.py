@@ -39,7 +39,7 @@ def test_default_line_has_the_contract_fields_and_a_verified_frame():
     assert d["fast_math"]["kernel"].startswith("fast_build::") and d["fast_math"]["within_1_pct"] >= 99.9
 
 
-@pytest.mark.parametrize("config,kernel", [("2", "render_pt_strip_kernel<false,false,false,true>"), ("parity", "render_parity_kernel<"), ("5", "render_pt_pool_kernel<1024,")])
+@pytest.mark.parametrize("config,kernel", [("2", "render_pt_stream_kernel<false>"), ("parity", "render_parity_kernel<"), ("5", "render_pt_pool_kernel<1024,")])
 def test_other_configs_emit_the_same_shape(config, kernel):
     d = _bench("--config", config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
     assert CONTRACT <= set(d) and d["roofline"]["kernel"].startswith(kernel)

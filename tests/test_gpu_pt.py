@@ -12,6 +12,11 @@ import weekend_raytracer_wgpu_amd as m
 from helpers import GOLDEN, assert_images_equal, scene_data, simple_camera
 
 pytestmark = pytest.mark.gpu
+
+
+def _lane_per_pixel(kernel: str) -> bool:
+    """The lane-per-pixel schedule: the strip kernel's BY_PIXEL build, or -- flat scenes from 16 spp on -- its streaming build."""
+    return kernel.startswith("render_pt_stream_kernel<") or ("strip" in kernel and kernel.endswith(",true>"))
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tools"))
 GOLD = np.load(GOLDEN / "images_v1.npz")
@@ -177,6 +182,51 @@ def test_hosek_sky_blob(gpu_ctx, oracle):
         assert_images_equal(got, oracle.render(sd, p), f"hosek flags={flags}")
         os_ = oracle.stats()
         assert {k: gs[k] for k in COUNTERS} == {k: os_[k] for k in COUNTERS}
+
+
+def _sky_blob():
+    sky = m._abi.MirtSkyState()
+    for c in range(3):
+        for i, v in enumerate([-1.1, -0.3, 0.5, 1.2, -2.5, 0.4, 0.2, 1.5, 0.6]):
+            sky.params[9 * c + i] = v * (1.0 + 0.1 * c)
+        sky.radiances[c] = 1.0 + c
+    sky.sun_direction[:] = [0.0, 0.6, 0.8, 0.0]
+    return sky
+
+
+@pytest.mark.parametrize("scene,w,h,spp,bounces", [("three_spheres", 131, 23, 16, 8), ("three_spheres", 96, 64, 17, 1), ("main_rs_scene", 70, 41, 24, 2),
+                                                     ("single_sphere", 523, 127, 100, 8), ("single_sphere", 397, 170, 401, 50), ("earth", 80, 45, 30, 8)])
+def test_streaming_lane_per_pixel_build_vs_oracle(oracle, scene, w, h, spp, bounces, monkeypatch):
+    """render_pt_stream_kernel (flat scenes from 16 spp on): a lane whose path has ended starts its pixel's next sample without waiting for
+    the other lanes' paths.  Same samples, same exact sums: the frame is the oracle's at every sample count / bounce limit / ragged size,
+    with the RTIOW sky and with a Hosek blob, under a seed and a sample offset, through the accumulation buffer and with the reference's
+    per-frame stream -- and byte for byte the frame of the plain lane-per-pixel build (MIRT_STREAM=0)."""
+    sd = scene_data(scene, w, h)
+    ctx = m.Context(0)
+    monkeypatch.setenv("MIRT_STREAM", "0")
+    plain = m.Context(0)                                       # tuning knobs are read once, in mirt_ctx_create
+    monkeypatch.delenv("MIRT_STREAM")
+    try:
+        for sky in (None, _sky_blob()):
+            sd.sky = sky
+            ctx.set_scene(sd)
+            plain.set_scene(sd)
+            flags = m.MIRT_FLAG_SKY_HOSEK if sky is not None else 0
+            for kw in (dict(), dict(seed=0xFEEDFACE, sample_begin=7), dict(frame_spp=1), dict(frame_spp=spp)):
+                p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=flags, **kw)
+                got = ctx.render(p)
+                assert ctx.last_kernel() == ("render_pt_stream_kernel<true>" if sky is not None else "render_pt_stream_kernel<false>")
+                assert_images_equal(got, oracle.render(sd, p), f"{scene} {w}x{h} spp {spp} bounces {bounces} {kw} sky {sky is not None}")
+                assert np.array_equal(plain.render(p), got) and plain.last_kernel().startswith("render_pt_strip_kernel<false,")
+            p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=flags)
+            ctx.accum_reset(p)
+            ctx.accum_add(p)
+            ctx.accum_add(p)                                   # the second add continues the sample range
+            want = oracle.render_pt_sums(sd, m.make_params(w, h, 2 * spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, flags=flags))
+            assert np.array_equal(ctx.accum_read(p), want)
+    finally:
+        ctx.close()
+        plain.close()
 
 
 @pytest.mark.parametrize("kernel,spp", [(m.MIRT_FLAG_KERNEL_POOL, 32), (m.MIRT_FLAG_KERNEL_STRIP, 8), (0, 100)])
@@ -383,7 +433,7 @@ def test_lane_per_pixel_units_with_sample_groups(oracle, groups, monkeypatch):
             ctx.set_scene(sd)
             p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=6, flags=flags)
             got = ctx.render(p)
-            assert ctx.last_kernel().endswith(",true>") and "strip" in ctx.last_kernel(), ctx.last_kernel()
+            assert _lane_per_pixel(ctx.last_kernel()), ctx.last_kernel()
             assert_images_equal(got, oracle.render(sd, p), f"{scene} {w}x{h} spp {spp}, {1 << (groups - 1)} sample groups")
         # progressive accumulation through the same kernel: two adds of 16 samples == the oracle's sums of 32
         sd = scene_data("three_spheres", 70, 9)
@@ -563,7 +613,7 @@ def test_reference_frame_stream_vs_oracle(gpu_ctx, oracle, scene, w, h, spp, n):
     for flags in (0, m.MIRT_FLAG_KERNEL_POOL, LINEAR | m.MIRT_FLAG_COUNT_WORK):
         p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, flags=flags, frame_spp=n)
         got = gpu_ctx.render(p)
-        assert gpu_ctx.last_kernel().endswith(",true>") and "strip" in gpu_ctx.last_kernel()
+        assert _lane_per_pixel(gpu_ctx.last_kernel()), gpu_ctx.last_kernel()
         gs = gpu_ctx.stats()
         want = oracle.render(sd, p)
         assert_images_equal(got, want, f"{scene} frame_spp {n} flags {flags}")
@@ -694,10 +744,11 @@ def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):
         gpu_ctx.set_scene(scene_data(scene, w, h))
         gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8))
         return gpu_ctx.last_kernel()
-    assert kernel("three_spheres", 640, 360, 28) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("three_spheres", 640, 360, 12) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("three_spheres", 640, 360, 28) == "render_pt_stream_kernel<false>"
     assert kernel("three_spheres", 640, 360, 32).startswith("render_pt_pool_kernel<256,112,6,")
-    assert kernel("single_sphere", 640, 360, 100) == "render_pt_strip_kernel<false,false,false,true>"
-    assert kernel("single_sphere", 640, 360, 792) == "render_pt_strip_kernel<false,false,false,true>"
+    assert kernel("single_sphere", 640, 360, 100) == "render_pt_stream_kernel<false>"
+    assert kernel("single_sphere", 640, 360, 792) == "render_pt_stream_kernel<false>"
     assert kernel("single_sphere", 640, 360, 800).startswith("render_pt_pool_kernel<256,112,6,")
     assert kernel("single_sphere", 64, 36, 100) == "render_pt_strip_kernel<false,false,false,false>"      # tiny frame: lanes on samples
     assert kernel("rtiow_final", 640, 360, 12) == "render_pt_strip_kernel<false,false,true,true>"

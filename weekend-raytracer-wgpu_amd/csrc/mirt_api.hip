@@ -239,6 +239,8 @@ struct Tuning {
     int      pinhole = -1;            // MIRT_PINHOLE=0: never take the pinhole-camera shortcut (A/B runs)
     int      spread_units = -1;       // MIRT_SPREAD_UNITS=0: strip-type launches use one dispenser word (A/B runs)
     int      static_units = -1;       // MIRT_STATIC_UNITS=0/1: lane-per-pixel units dispensed to a persistent grid / one unit per wave (A/B runs, tests)
+    int      pool_min_spp = -1;       // MIRT_POOL_MIN_SPP=n: flat scenes take the pooled kernel from n samples per pixel on (A/B runs: the crossovers kPoolMinSpp*)
+    int      stream = -1;             // MIRT_STREAM=0/1: lane-per-pixel launches in flat scenes never / always run the streaming build (A/B runs)
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
@@ -262,6 +264,8 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_PINHOLE")) t.pinhole = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_SPREAD_UNITS")) t.spread_units = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_STATIC_UNITS")) t.static_units = (e[0] == '1') ? 1 : 0;
+    if (const char* e = std::getenv("MIRT_POOL_MIN_SPP")) { const int v = std::atoi(e); if (v >= 1) t.pool_min_spp = v; }
+    if (const char* e = std::getenv("MIRT_STREAM")) t.stream = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
@@ -899,7 +903,14 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // 16 for many-sphere scenes, where the pool's re-compaction of grid walks is worth most.
     const size_t lds_pool_block = scene_lds + pc.lds_bytes;
     const uint32_t pool_waves_per_cu = (uint32_t)(c->lds_per_cu / (lds_pool_block ? lds_pool_block : 1)) * (pc.threads / 64u);
-    const uint32_t pool_min_spp = c->n_shading_routines <= 1 ? mirt::kPoolMinSppOneRoutine : mirt::kPoolMinSpp;
+    // (round 4, the streaming build of lane = pixel: a single-routine scene on a frame of at least eight rounds of 16-pixel units per resident
+    //  wave -- 1 Mpixel on 256 CUs -- never takes the pool: single sphere 1080p x 800 / 2000 / 4000 spp 5.38 / 13.3 / 26.5 ms against the pool's
+    //  6.34 / 15.5 / 31.2, 3840x2160 x 1000 spp 26.3 / 30.5; at 800x600 x 1000 spp the pool still wins, 2.17 against 2.31.  Scenes with several
+    //  routines: streaming 1.16 ms at 32 spp, pool 1.17; 36 / 48 spp 1.28 / 1.61 against 1.24 / 1.50 -- the crossover stays.  r04_lowspp_ab.txt block 9)
+    const bool stream_any_spp = c->n_shading_routines <= 1 && !hosek && npix >= 16ull * 8u * 32u * (uint64_t)c->cu_count;
+    const uint32_t pool_min_spp = tune.pool_min_spp > 0 ? (uint32_t)tune.pool_min_spp
+                                : stream_any_spp ? UINT32_MAX
+                                : c->n_shading_routines <= 1 ? mirt::kPoolMinSppOneRoutine : mirt::kPoolMinSpp;
     bool pool = pt && p->spp >= pool_min_spp && c->n_shading_routines >= 1 && pool_waves_per_cu >= 16;
     if (p->flags & MIRT_FLAG_KERNEL_STRIP) pool = false;
     if (p->flags & MIRT_FLAG_KERNEL_POOL) pool = pt;
@@ -1013,6 +1024,10 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     if (!pt) by_pixel = (p->flags & MIRT_FLAG_KERNEL_STRIP) ? false : (tune.by_pixel >= 0 ? tune.by_pixel == 1 : true);
     a.static_units = 0;
     a.px_groups_log2 = 0;
+    // lane = pixel in a flat scene from 16 spp on: the streaming build -- a lane starts its pixel's next sample without waiting for the wave
+    // (mirt_kernels.hip: strip_kernel_body<STREAM>; MIRT_STREAM=0/1 for A/B runs)
+    a.stream_samples = (pt && by_pixel && !count && !use_grid && p->spp >= 16u) ? 1u : 0u;
+    if (tune.stream >= 0 && pt && by_pixel && !count && !use_grid) a.stream_samples = (uint32_t)tune.stream;
     if (by_pixel) {
         // Path-traced lane-per-pixel units: 64 pixels x all samples -- or 32 / 16 pixels with the samples dealt to 2 / 4 groups of lanes:
         // smaller units are more units, and the last unit of a wave is then a smaller part of its life (config 2, 1080p x 100 spp, had 4
@@ -1024,7 +1039,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         if (pt && !frame_stream && tune.px_groups != 0) {
             // (round 4, one unit per wave, profiles/r04_lowspp_ab.txt block 4: two groups from shares of 4 -- three spheres 8 spp 0.337 ms against
             //  0.359, main.rs scene 0.434 / 0.459 --, four groups from shares of 6: 16 spp 0.610 with two groups, 0.617 with four; 24 spp 0.884 / 0.881)
-            const uint32_t min_share[2] = { 4u, use_grid ? 4u : 6u };
+            // (streaming launches, below: shares of at least 8 samples -- three spheres 16 spp 0.588 ms with two groups, 0.643 with four; 24 spp
+            //  0.822 / 0.886; config 2 at 25 per lane, four groups: 0.750, two: 0.829, eight (128 spp): +-0; block 9)
+            const uint32_t min_share[2] = { a.stream_samples ? 8u : 4u, a.stream_samples ? 8u : (use_grid ? 4u : 6u) };
             while (a.px_groups_log2 < 2u && p->spp % (2u << a.px_groups_log2) == 0u && (p->spp >> (a.px_groups_log2 + 1u)) >= min_share[a.px_groups_log2])
                 a.px_groups_log2 += 1u;
             if (tune.px_groups > 0 && p->spp % (1u << (tune.px_groups - 1)) == 0u) a.px_groups_log2 = (uint32_t)tune.px_groups - 1u;
@@ -1066,8 +1083,8 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         // kernels).  A block beyond that would hold its first unit until the dispenser has run dry and run it alone at the end.
         const bool fast_strip = pt && !count && (p->flags & MIRT_FLAG_FAST_MATH);
         uint32_t per_cu = !pt ? kx::parity_blocks_per_cu(count, by_pixel, a.lds_bytes)
-                        : fast_strip ? kf::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes)
-                                     : kx::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes);
+                        : fast_strip ? kf::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes, a.stream_samples != 0u)
+                                     : kx::strip_blocks_per_cu(hosek, count, use_grid, by_pixel, a.lds_bytes, a.stream_samples != 0u);
         if (per_cu > 8u) per_cu = 8u;                                 // 2048 threads per CU / 256
         const uint32_t resident = (uint32_t)c->cu_count * per_cu;
         // ... unless the launch runs one unit per wave (a.static_units): then the grid is the units (MIRT_STATIC_GRID=k, A/B runs: k x the
@@ -1115,8 +1132,9 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
         snprintf(c->last_kernel, sizeof c->last_kernel, "%s%s", fast ? "fast_build::" : "", kname);
     } else {
         HIP_TRY(fast ? kf::launch_pt_strip(a, blocks, count, use_grid, by_pixel, on) : kx::launch_pt_strip(a, blocks, count, use_grid, by_pixel, on));
-        snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
-                 tf[use_grid], tf[by_pixel]);
+        if (a.stream_samples) snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_stream_kernel<%s>", fast ? "fast_build::" : "", tf[hosek]);
+        else snprintf(c->last_kernel, sizeof c->last_kernel, "%srender_pt_strip_kernel<%s,%s,%s,%s>", fast ? "fast_build::" : "", tf[count], tf[hosek],
+                      tf[use_grid], tf[by_pixel]);
     }
     // The kernel is enqueued: from here on the slot is in use, whatever happens below (a failure after this point must not hand the
     // slot -- its dispenser words no longer zero -- to the next launch: poison_slot).

@@ -136,6 +136,10 @@ constexpr uint32_t kGridPoolSlotChoices[4] = { MIRT_GRID_SLOTS };   // the large
 //   round 4 (lane-per-pixel launches run one unit per wave; profiles/r04_lowspp_ab.txt block 5): several routines: strip 0.96 / 1.10 / 1.27 /
 //     1.52 ms at 24 / 28 / 32 / 40 spp, pool 1.01 / 1.12 / 1.20 / 1.39 (main.rs scene 1.26 / 1.66 against 1.32 / 1.56 at 24 / 32)             -> 32
 //     ONE routine: strip 3.36 / 4.81 / 6.49 / 8.11 ms at 400 / 600 / 800 / 1000 spp, pool 3.80 / 5.25 / 6.52 / 7.93                           -> 800
+//     with the streaming build of lane = pixel (from 16 spp on; block 9): several routines: 0.94 / 1.16 / 1.28 / 1.61 ms at 28 / 32 / 36 / 48 spp, pool
+//     - / 1.17 / 1.24 / 1.50                                                                                                                  -> 32
+//     ONE routine: 5.38 / 13.3 / 26.5 ms at 800 / 2000 / 4000 spp, pool 6.34 / 15.5 / 31.2; 3840x2160 x 1000 spp 26.3 against 30.5 -> frames of
+//     >= 1 Mpixel never take the pool (mirt_api.hip: stream_any_spp); 800x600 x 1000 spp 2.31 against the pool's 2.17                          -> 800 below that
 constexpr uint32_t kPoolMinSpp           = 32;
 constexpr uint32_t kPoolMinSppOneRoutine = 800;
 constexpr uint32_t kPoolMinSppGrid       = 16;
@@ -191,6 +195,7 @@ struct RenderArgs {
     uint32_t queue_routine[5];             // pool kernel: scatter queue q runs routine queue_routine[q] = min(GpuMaterial.id, 4)
     uint32_t lds_bytes;
     uint32_t launch_threads;               // strip-type kernels: threads per block of THIS launch (0: kBlockThreads)
+    uint32_t stream_samples;               // lane-per-pixel strip launch in a flat scene: 1 = render_pt_stream_kernel (a lane starts its next sample without waiting for the wave)
     float    sph3[12];                     // scenes of exactly three spheres: their {centre, r^2} records as kernel arguments (scalar loads)
 };
 
@@ -215,14 +220,14 @@ struct LaunchOn {
 struct PoolConfig { uint32_t threads, slots, lds_bytes; };
 namespace fast_build {
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream);
-uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes);
+uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes, bool stream);
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, LaunchOn stream);
 }
 namespace exact_build {
 hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, bool by_pixel, LaunchOn stream);
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream);
 // blocks of the kernel such a launch runs that are resident per CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
-uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes);
+uint32_t   strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes, bool stream);
 uint32_t   parity_blocks_per_cu(bool count, bool by_pixel, uint32_t lds_bytes);
 uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);

@@ -1495,9 +1495,17 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
 // would spill and keeps its registers.  The grid build of the same schedule (many-sphere scenes below 16 spp) runs 7 waves
 // per SIMD at 72 VGPRs instead of 5 at 90, a few spilled registers included: RTIOW 2 / 8 spp 0.66 -> 0.62 / 1.92 -> 1.74 ms
 // (6 waves -2 / -6 %, 8 waves -5 / -8 %).
-template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL = false>
-__global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOSEK) ? 8 : ((BY_PIXEL && !COUNT && GRID) ? 7 : 1)) void render_pt_strip_kernel(RenderArgs A)
+//
+// STREAM (lane = pixel, flat scenes; render_pt_stream_kernel): the lanes do not wait for each other between samples.  A lane whose path has
+// ended takes its pixel's NEXT sample as soon as kStreamRefillMin lanes of the wave want one (or none has a live path), so a wave lasts as long
+// as its lane with the longest SUM of path lengths, not the sum over samples of the longest path.  It pays from 8 samples per lane on
+// (profiles/r04_lowspp_ab.txt block 9: config 2 -7 %, three spheres 16 / 24 spp -3 / -7 %; below that the fresh camera rays it mixes with old
+// paths make a step run more shading routines than it saves steps: 2 / 8 spp +10 / +4 %).  Same samples, same exact integer sums.
+constexpr uint32_t kStreamRefillMin = 16;
+template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL, bool STREAM>
+MIRT_DEV void strip_kernel_body(const RenderArgs& A)
 {
+    static_assert(!STREAM || (BY_PIXEL && !GRID && !COUNT), "the streaming schedule exists for lane = pixel in flat scenes");
     extern __shared__ __align__(16) unsigned char smem[];
     // many-sphere scenes (GRID build): the material table (one 48-byte read per hit) stays in global memory / L2
     // so that LDS holds only what every sphere TEST reads, and more waves fit a CU
@@ -1554,6 +1562,57 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
                 n_cand = __builtin_amdgcn_readfirstlane(n_cand);
                 cand = my_cand;
             }
+            if constexpr (STREAM) {
+                uint32_t j = 0;
+                const uint32_t n_lane = (inside && A.num_bounces != 0u) ? n_mine : 0u;
+                bool alive = false;
+                f3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), thr = mk(1, 1, 1);
+                uint32_t bounce = 0;
+                for (;;) {
+                    const bool want = !alive && j < n_lane;
+                    const unsigned long long wm = ballot_(want), am = ballot_(alive);
+                    if ((wm | am) == 0ull) break;
+                    if (am == 0ull || (uint32_t)__popcll(wm) >= kStreamRefillMin) {
+                        if (want) {
+                            const CamRegs C = load_camera(S, A);
+                            const uint32_t sample = s_first + j;
+                            if (A.frame_spp == 0u) {
+                                generate_primary(A, C, x, y, sample, rng, ro, rd);
+                            } else {
+                                if (sample % A.frame_spp == 0u)
+                                    rng.state = jenkins_hash(((x + y * A.width) ^ jenkins_hash(A.frame_begin + sample / A.frame_spp + 1u)) ^ A.seed_mix);
+                                generate_primary<false>(A, C, x, y, sample, rng, ro, rd);
+                            }
+                            thr = mk(1, 1, 1);
+                            bounce = 0;
+                            alive = true;
+                            ++j;
+                        }
+                    }
+                    float closest;
+                    const int best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
+                    if (alive) {
+                        if (best >= 0) {
+                            const PreparedSphere sp = S.spheres[best];
+                            const f3 hp = fma3(closest, rd, ro);
+                            const f3 hn = sp.inv_r * (hp - mk(sp.cx, sp.cy, sp.cz));
+                            const PreparedMaterial* m = &S.pmats[sp.material_idx];
+                            const Scattered sc = shade_by_id<COUNT>(A, m, m->id, true, rd, hp, hn, rng, work);
+                            ro = hp;
+                            rd = sc.dir;
+                            thr = thr * sc.att;
+                            ++bounce;
+                            if (bounce >= A.num_bounces) alive = false;
+                        } else {
+                            const f3 c = thr * sky_color<HOSEK>(S, rd);
+                            acc_r += to_fixed(c.x);
+                            acc_g += to_fixed(c.y);
+                            acc_b += to_fixed(c.z);
+                            alive = false;
+                        }
+                    }
+                }
+            } else
             for (uint32_t j = 0; j < n_mine; ++j) {
                 f3 ro, rd;
                 {
@@ -1627,6 +1686,18 @@ __global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOS
         }
         work.flush(A.counters, lane);
     }
+}
+
+template <bool COUNT, bool HOSEK, bool GRID, bool BY_PIXEL = false>
+__global__ __launch_bounds__(kBlockThreads, (BY_PIXEL && !COUNT && !GRID && !HOSEK) ? 8 : ((BY_PIXEL && !COUNT && GRID) ? 7 : 1)) void render_pt_strip_kernel(RenderArgs A)
+{
+    strip_kernel_body<COUNT, HOSEK, GRID, BY_PIXEL, false>(A);
+}
+
+template <bool HOSEK>
+__global__ __launch_bounds__(kBlockThreads, HOSEK ? 6 : 8) void render_pt_stream_kernel(RenderArgs A)
+{
+    strip_kernel_body<false, HOSEK, false, true, true>(A);
 }
 
 // Shading routines a path can wait for: the five scatter routines of scatterRay (wgsl:174-314), identified by
@@ -1816,8 +1887,9 @@ hipError_t launch_parity(const RenderArgs& a, uint32_t grid_blocks, bool count, 
 using StripKernel = void (*)(RenderArgs);
 
 // the build of the strip kernel a launch runs (nullptr: no such build -- counting launches of the fast-math library)
-static StripKernel strip_kernel(bool count, bool hosek, bool use_grid, bool by_pixel)
+static StripKernel strip_kernel(bool count, bool hosek, bool use_grid, bool by_pixel, bool stream = false)
 {
+    if (stream && by_pixel && !count && !use_grid) return hosek ? render_pt_stream_kernel<true> : render_pt_stream_kernel<false>;
 #ifdef MIRT_FAST_MATH
     if (count) return nullptr;                           // the counting builds exist in the exact build only
 #else
@@ -1835,7 +1907,7 @@ static StripKernel strip_kernel(bool count, bool hosek, bool use_grid, bool by_p
 
 hipError_t launch_pt_strip(const RenderArgs& a, uint32_t grid_blocks, bool count, bool use_grid, bool by_pixel, LaunchOn stream)
 {
-    const StripKernel k = strip_kernel(count, (a.flags & MIRT_FLAG_SKY_HOSEK) != 0, use_grid, by_pixel);
+    const StripKernel k = strip_kernel(count, (a.flags & MIRT_FLAG_SKY_HOSEK) != 0, use_grid, by_pixel, a.stream_samples != 0u);
     if (!k) return hipErrorInvalidValue;
     return launch_with_lds(k, dim3(grid_blocks), dim3(a.launch_threads ? a.launch_threads : kBlockThreads), a, stream);
 }
@@ -1863,9 +1935,9 @@ static uint32_t blocks_per_cu(const void* kernel, uint32_t threads, uint32_t lds
     return blocks;
 }
 
-uint32_t strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes)
+uint32_t strip_blocks_per_cu(bool hosek, bool count, bool use_grid, bool by_pixel, uint32_t lds_bytes, bool stream)
 {
-    const StripKernel k = strip_kernel(count, hosek, use_grid, by_pixel);
+    const StripKernel k = strip_kernel(count, hosek, use_grid, by_pixel, stream);
     return k ? blocks_per_cu(reinterpret_cast<const void*>(k), kBlockThreads, lds_bytes) : 1u;
 }
 
