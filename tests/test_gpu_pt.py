@@ -291,7 +291,7 @@ def test_random_scenes_materials_and_cameras(gpu_ctx, oracle, seed):
     material tables (every routine incl. the missing-material one, random fuzz / refraction index, 1x1 and
     image textures), random cameras (aperture 0 and wide, any pose).  Every schedule of the library must give
     the oracle's exact 64-bit sums -- with 1 to 5 routines present the pool kernel's 4- and 6-queue builds,
-    the lane-per-sample and the lane-per-pixel strip schedules are all exercised."""
+    the lane-per-sample and the lane-per-pixel strip schedules (plain and streaming) are all exercised."""
     rng = np.random.default_rng(500 + seed)
     T = m.Texture
     img = (rng.random((6, 10, 3)) * 255).astype(np.uint8)
@@ -318,7 +318,7 @@ def test_random_scenes_materials_and_cameras(gpu_ctx, oracle, seed):
                                0.0 if rng.random() < 0.4 else float(rng.uniform(0.0, 1.0)), float(rng.uniform(1, 10)))
     sd = m.SceneData(m.GpuCamera.new(fc.renderer_camera(), (w, h)).c, spheres, gm, texels)
     gpu_ctx.set_scene(sd)
-    for spp, flags in ((3, 0), (11, 0), (64, m.MIRT_FLAG_KERNEL_STRIP), (64, m.MIRT_FLAG_KERNEL_POOL), (50, 0)):
+    for spp, flags in ((3, 0), (11, 0), (24, 0), (64, m.MIRT_FLAG_KERNEL_STRIP), (64, m.MIRT_FLAG_KERNEL_POOL), (50, 0)):     # 24: the streaming build
         bounces = int(rng.integers(1, 10))
         p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=bounces, seed=seed, flags=flags)
         gpu_ctx.accum_reset(p)
