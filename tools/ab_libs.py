@@ -31,12 +31,13 @@ ap.add_argument("--spp", type=int, default=1000)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--flags", type=lambda s: int(s, 0), default=0)
 ap.add_argument("--mode", default="pt")
+ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--allow-diff", action="store_true")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 w, h = map(int, a.size.split("x"))
 sd = layer_scene_data(w, h) if a.scene == "layer_scene" else scene_data(a.scene, w, h)
-p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT if a.mode == "pt" else m.MIRT_MODE_PARITY, num_bounces=8, flags=a.flags)
+p = m.make_params(w, h, a.spp, mode=m.MIRT_MODE_PT if a.mode == "pt" else m.MIRT_MODE_PARITY, num_bounces=a.bounces, flags=a.flags)
 
 libs = []
 for spec in a.libs:

@@ -66,6 +66,9 @@ MIRT_DEV SceneLds stage_scene(const RenderArgs& A, unsigned char* smem, bool hos
     const uint4* src_mat = PT ? reinterpret_cast<const uint4*>(A.pmats) : reinterpret_cast<const uint4*>(A.mats);
     const uint4* src_sky = reinterpret_cast<const uint4*>(A.sky);
     const uint32_t total = n_cam + n_sph + n_mat + n_sky;
+#ifdef MIRT_PROBE_NOSTAGE      // experiment builds only: what does staging cost a short launch?  (the frame is garbage)
+    if (A.width == 0xffffffffu)
+#endif
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
         uint4 v;
         if (i < n_cam) { const u32x4 q = src_cam[i]; v = make_uint4(q.x, q.y, q.z, q.w); }
@@ -1641,6 +1644,9 @@ MIRT_DEV void strip_kernel_body(const RenderArgs& A)
                 if (AS.accum) {                  // progressive mode: add the exact sums, resolve later
                     AS.accum[3ull * pi + 0] += acc_r; AS.accum[3ull * pi + 1] += acc_g; AS.accum[3ull * pi + 2] += acc_b;
                 } else {
+#ifdef MIRT_PROBE_NOSTORE      // experiment builds only
+                    if (acc_r == 0x123456789abcull)
+#endif
                     AS.out[pi] = pack_rgba(resolve_channel(acc_r, AS.spp, AS.flags), resolve_channel(acc_g, AS.spp, AS.flags),
                                            resolve_channel(acc_b, AS.spp, AS.flags));
                 }
