@@ -112,6 +112,8 @@ constexpr uint32_t kByPixelMaxSpp = 64;   // strip kernel: below this many sampl
 // is staged once for all 16 waves and the rest of the 160 KB goes to the path pools.  Measured on RTIOW 1080p x 128 spp:
 // 512 threads x 112 slots, two blocks 17.3 ms; x 128 slots 16.6; 1024 x 144 15.9; 1024 x 152 15.7; one 512-thread
 // block per CU (8 waves) with 160-256 slots 26.3 -- the pools want to be as large as 16 resident waves allow.
+// 160 slots are the first choice where a small blob leaves room for them (they cost nothing there); on RTIOW a blob shrunk until they
+// fit measured +-0 against 152 (profiles/r04_c5_ab.txt block 4), which is why plan_grid coarsens cells only until 152 fit, not 160.
 // (experiment builds: -DMIRT_GRID_THREADS=640 -DMIRT_GRID_BLOCKS=2 -DMIRT_GRID_MINW=5 "-DMIRT_GRID_SLOTS=104,96,88,80" = 20 waves per CU)
 #ifndef MIRT_GRID_THREADS
 #define MIRT_GRID_THREADS 1024
