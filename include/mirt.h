@@ -140,11 +140,12 @@ enum {
     MIRT_FLAG_NO_SRGB        = 1u << 2, /* skip the sRGB OETF the Bgra8UnormSrgb surface applies (main.rs:465) */
     MIRT_FLAG_COUNT_WORK     = 1u << 3, /* run the counting build of the kernel: fills MirtStats work counters */
     /* Scheduling of the path-traced kernel (the image is bit-identical either way).  Default: the pooled kernel
-     * (paths queued by shading routine in LDS) from a measured number of samples per pixel on -- 28 for scenes with
-     * several shading routines, 600 for scenes with one, 16 for many-sphere scenes (csrc/mirt_kernels.h, kPoolMinSpp*)
-     * -- and the strip kernel below (lane = pixel under 64 samples per pixel, else lane = sample).
-     * In parity mode MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule (default below 64 samples per pixel:
-     * lane = pixel, the shape of the reference's 2-spp operating point); the image is the same. */
+     * (paths queued by shading routine in LDS) from a measured number of samples per pixel on -- 32 for scenes with
+     * several shading routines, 16 for many-sphere scenes; scenes with ONE routine only on frames below 1 Mpixel, from
+     * 800 (csrc/mirt_kernels.h, kPoolMinSpp*) -- and the strip kernel below: lane = pixel (from 16 samples per pixel on
+     * in flat scenes its streaming build, render_pt_stream_kernel), lane = sample for counting launches.
+     * In parity mode MIRT_FLAG_KERNEL_STRIP forces the lane = sample schedule (default: lane = pixel, the shape of the
+     * reference's 2-spp operating point, at every sample count); the image is the same. */
     MIRT_FLAG_KERNEL_STRIP   = 1u << 4, /* force the strip kernel (wave = 64 samples of one pixel) */
     MIRT_FLAG_KERNEL_POOL    = 1u << 5, /* force the pooled kernel */
     MIRT_FLAG_NO_GRID        = 1u << 6, /* many-sphere scenes: scan the flat sphere list instead of the uniform grid */

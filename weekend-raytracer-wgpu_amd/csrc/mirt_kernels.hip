@@ -1346,7 +1346,7 @@ MIRT_DEV float uncharted2_tonemap(float x)   // wgsl:94-103
 
 MIRT_DEV uint32_t resolve_channel(unsigned long long sum, uint32_t n_samples, uint32_t flags)
 {
-    // mean = sum / (n * 2^20), in double, rounded once to float (the oracle's expression).  A power-of-two sample count -- the reference adds
+    // mean = sum / (n * 2^20), in double, rounded once to float (mirt-math v1's definition of the mean).  A power-of-two sample count -- the reference adds
     // 2 per frame -- makes the divisor a power of two: the quotient is an exact scaling of (double)sum (one v_ldexp_f64), without the f64
     // division (about 20 of the ~105 instructions of a channel).  Wave-uniform choice; n_samples >= 1.
     const double denom = (double)n_samples * 1048576.0;
