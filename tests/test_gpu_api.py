@@ -311,6 +311,29 @@ def test_accum_resolve_waits_for_adds_on_a_caller_stream(gpu_ctx, oracle):
     assert np.array_equal(sums, oracle.render_pt_sums(sd, want))
 
 
+def test_accumulation_on_the_default_stream_then_resolve(gpu_ctx, oracle):
+    """The reference's progressive loop queued on torch's CURRENT stream when no side stream is set -- handle 0, which the binding passes
+    as hipStreamLegacy -- then resolved: frames of 2 samples per pixel drawn from the shader's per-frame RNG stream, resolve and read after
+    every few of them.  (Round 4: accum_resolve made the context's stream wait for an event recorded on the legacy stream with
+    hipStreamWaitEvent, which crashes inside the HIP runtime; the host waits for the event now.)"""
+    import torch
+    w, h = 160, 90
+    sd = scene_data("main_rs_scene", w, h)
+    gpu_ctx.set_scene(sd)
+    st = torch.cuda.current_stream().cuda_stream
+    assert st == 0
+    p = m.make_params(w, h, 2, mode=m.MIRT_MODE_PT, frame_spp=2)
+    gpu_ctx.accum_reset(p)
+    for frames in (1, 4, 16):
+        while gpu_ctx.accum_samples() < 2 * frames:
+            gpu_ctx.accum_add(p, st)
+        got = gpu_ctx.accum_resolve(p)                   # no explicit sync by the caller
+        sums = gpu_ctx.accum_read(p)
+        want = m.make_params(w, h, 2 * frames, mode=m.MIRT_MODE_PT, frame_spp=2)
+        assert_images_equal(got, oracle.render(sd, want), f"{frames} frames of 2 spp on the default stream")
+        assert np.array_equal(sums, oracle.render_pt_sums(sd, want))
+
+
 def test_set_scene_is_failure_atomic(gpu_ctx):
     """A set_scene that fails (here: rejected up front) or half-fails leaves the context without a scene
     rather than with stale tables: the next render must answer MIRT_ERR_NO_SCENE or render the OLD scene whole."""

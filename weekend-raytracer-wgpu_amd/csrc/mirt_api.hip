@@ -1322,7 +1322,10 @@ int mirt_ctx_accum_resolve(MirtContext* c, const MirtParams* p, uint8_t* out, si
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = ensure_capacity(&c->d_out, &c->cap_out, (size_t)c->accum_pixels)) != MIRT_OK) return rc;
-    if (c->accum_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_accum, 0));   // adds may sit on a caller stream
+    // adds may sit on a caller stream: the HOST waits for the last of them (this call blocks anyway).  Never hipStreamWaitEvent here: with the
+    // event recorded on the legacy default stream (torch's current stream when no side stream is set) that call crashes inside the HIP
+    // runtime of ROCm 7.2 (tests/test_gpu_api.py::test_accumulation_on_the_default_stream_then_resolve).
+    if (c->accum_pending) { HIP_TRY(hipEventSynchronize(c->ev_accum)); c->accum_pending = false; }
     HIP_TRY(kx::launch_resolve(c->d_accum, c->d_out, c->accum_pixels, c->accum_samples, p->flags, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)c->accum_pixels * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
