@@ -549,3 +549,110 @@ def test_scene_limits_at_the_boundary(gpu_ctx):
     with pytest.raises(m.MirtError) as e:
         gpu_ctx.set_scene(m.SceneData(cam, _soup(4096, 0, 8.0), mats, tex))
     assert e.value.status == _abi.MIRT_ERR_SCENE_TOO_LARGE
+
+
+_SEQ0 = int(os.environ.get("MIRT_SEQ_FIRST_SEED", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_SEQ0, _SEQ0 + int(os.environ.get("MIRT_SEQ_SEEDS", "6"))))      # soaks: MIRT_SEQ_SEEDS=200
+def test_random_call_sequences_keep_the_context_consistent(oracle, seed):
+    """The boundary as a state machine: ~70 random calls per seed against ONE context -- set_scene, set_camera, blocking renders, device
+    renders queued on the context's stream / the legacy default stream / two side streams (checked only at the next synchronisation point, so
+    they overlap), progressive accumulation (reset / add / resolve / read), get_stats, set_timing, synchronize -- in both modes, every
+    schedule the sample count and flags select, dispensed and one-unit-per-wave launches.  Every frame and every sum must be the oracle's
+    for the scene and camera that were current WHEN THE CALL WAS ISSUED."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(40, 120)), int(rng.integers(24, 70))
+    names = ["three_spheres", "main_rs_scene", "single_sphere", "rtiow_final", "layer"]
+
+    def load(name):
+        return layer_scene_data(w, h) if name == "layer" else scene_data(name, w, h)
+
+    def with_camera(sd, cam):
+        return m.SceneData(cam, sd.spheres, sd.materials, sd.texels, sd.sky)
+
+    ctx = _context_with_dispensed_units() if rng.random() < 0.5 else m.Context(0)
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [None, 0, side[0].cuda_stream, side[1].cuda_stream]
+    sd = load(names[int(rng.integers(len(names)))])
+    ctx.set_scene(sd)
+    pending = []                                   # (device buffer, expected frame, what) of renders not yet synchronised
+    acc = None                                     # (params of the epoch, stream of the epoch, scene at reset) of the running accumulation
+
+    def params():
+        pt = len(sd.materials) < 3 or rng.random() < 0.75           # (the parity loop reads material_data[2], layer.rs:345-349)
+        spp = int(rng.choice([1, 2, 3, 5, 8, 16, 24, 40, 70]))
+        if len(sd.spheres) > 100:
+            spp = min(spp, 24)                                       # (keeps the checker's flat scan of a many-sphere scene short)
+        flags = 0
+        if pt:
+            flags = int(rng.choice([0, 0, 0, m.MIRT_FLAG_KERNEL_STRIP, m.MIRT_FLAG_KERNEL_POOL, m.MIRT_FLAG_NO_TONEMAP, m.MIRT_FLAG_NO_SRGB]))
+            fs = int(rng.choice([0, 0, 1, spp]))
+            return m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=int(rng.integers(1, 9)), flags=flags, seed=int(rng.integers(0, 1 << 40)),
+                                 frame_spp=fs)
+        return m.make_params(w, h, min(spp, 24), mode=m.MIRT_MODE_PARITY, flags=int(rng.choice([0, m.MIRT_FLAG_KERNEL_STRIP])))
+
+    def drain():
+        torch.cuda.synchronize()
+        for buf, want, what in pending:
+            assert_images_equal(buf.cpu().numpy(), want, f"seed {seed}: {what}")
+        pending.clear()
+
+    try:
+        for step in range(70):
+            op = rng.choice(["scene", "camera", "render", "device", "device", "device", "reset", "add", "add", "resolve", "read", "stats", "timing", "sync"])
+            if op == "scene":
+                name = names[int(rng.integers(len(names)))]
+                sd = load(name)
+                ctx.set_scene(sd)                                  # waits for what is in flight (launches keep the tables they were issued with)
+                acc = None
+            elif op == "camera":
+                fc = m.FlyCameraController.default()
+                cam = fc.renderer_camera()
+                cam.eye_pos = cam.eye_pos + rng.normal(size=3).astype(np.float32) * 0.3
+                cam.aperture = float(rng.choice([0.0, cam.aperture, 0.3]))
+                gcam = m.GpuCamera.new(cam, (w, h)).c
+                ctx.set_camera(gcam)
+                sd = with_camera(sd, gcam)
+                acc = None                                         # (the sums of another view are not this one's: the host resets, as Raytracer does)
+            elif op == "render":
+                p = params()
+                assert_images_equal(ctx.render(p), oracle.render(sd, p), f"seed {seed} step {step}: blocking render")
+            elif op == "device":
+                p = params()
+                buf = torch.full((h, w, 4), 0xAB, dtype=torch.uint8, device="cuda")
+                torch.cuda.current_stream().synchronize()          # the fill must land before a side stream's kernel writes the buffer
+                st = streams[int(rng.integers(len(streams)))]
+                ctx.render_device(p, buf.data_ptr(), buf.numel(), st)
+                pending.append((buf, oracle.render(sd, p), f"step {step}: device render on stream {st}, {ctx.last_kernel()}"))
+                if len(pending) >= 6:
+                    drain()
+            elif op == "reset":
+                p = m.make_params(w, h, int(rng.choice([1, 2, 4, 16])), mode=m.MIRT_MODE_PT, num_bounces=int(rng.integers(1, 9)),
+                                  frame_spp=0, seed=int(rng.integers(0, 1 << 20)))
+                if rng.random() < 0.5:
+                    p.frame_spp = p.spp
+                ctx.accum_reset(p)
+                acc = (p, streams[int(rng.integers(len(streams)))], sd)
+            elif op == "add" and acc is not None:
+                ctx.accum_add(acc[0], acc[1])                      # one stream per epoch: adds must be ordered among themselves (mirt.h)
+            elif op in ("resolve", "read") and acc is not None and ctx.accum_samples() > 0:
+                p, _, sd0 = acc
+                total = m.make_params(w, h, ctx.accum_samples(), mode=m.MIRT_MODE_PT, num_bounces=p.num_bounces, frame_spp=p.frame_spp, seed=p.seed)
+                if op == "resolve":
+                    assert_images_equal(ctx.accum_resolve(p), oracle.render(sd0, total), f"seed {seed} step {step}: resolve after {ctx.accum_samples()} samples")
+                else:
+                    assert np.array_equal(ctx.accum_read(p), oracle.render_pt_sums(sd0, total)), f"seed {seed} step {step}: sums after {ctx.accum_samples()} samples"
+            elif op == "stats":
+                st = ctx.stats()
+                assert st["launches"] >= 0 and st["kernel_ms_total"] >= 0.0
+            elif op == "timing":
+                ctx.set_timing(bool(rng.integers(2)))
+            elif op == "sync":
+                ctx.synchronize()
+                drain()
+        drain()
+    finally:
+        torch.cuda.synchronize()
+        ctx.close()
