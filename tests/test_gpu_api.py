@@ -559,7 +559,8 @@ def test_random_call_sequences_keep_the_context_consistent(oracle, seed):
     """The boundary as a state machine: ~70 random calls per seed against ONE context -- set_scene, set_camera, blocking renders, device
     renders queued on the context's stream / the legacy default stream / two side streams (checked only at the next synchronisation point, so
     they overlap), progressive accumulation (reset / add / resolve / read), get_stats, set_timing, synchronize -- in both modes, every
-    schedule the sample count and flags select, dispensed and one-unit-per-wave launches.  Every frame and every sum must be the oracle's
+    schedule the sample count and flags select, dispensed and one-unit-per-wave launches, whole frames, bands of rows and single ranks' tiles
+    of N-way partitions.  Every frame and every sum must be the oracle's
     for the scene and camera that were current WHEN THE CALL WAS ISSUED."""
     import torch
     rng = np.random.default_rng(9000 + seed)
@@ -593,10 +594,24 @@ def test_random_call_sequences_keep_the_context_consistent(oracle, seed):
                                  frame_spp=fs)
         return m.make_params(w, h, min(spp, 24), mode=m.MIRT_MODE_PARITY, flags=int(rng.choice([0, m.MIRT_FLAG_KERNEL_STRIP])))
 
+    def partitioned(p):
+        """Sometimes a band of rows or one rank's tiles of an N-way partition (MirtParams.row_begin/row_end, tile_rows/n_parts/part)."""
+        r = rng.random()
+        if r < 0.15:
+            a, b = sorted(int(x) for x in rng.integers(0, h + 1, size=2))
+            if a < b:
+                p.row_begin, p.row_end = a, b
+        elif r < 0.3:
+            p.tile_rows, p.n_parts = int(rng.choice([1, 4, 16])), int(rng.integers(2, 9))
+            p.part = int(rng.integers(p.n_parts))
+            if m.params_out_rows(p) == 0:
+                p.tile_rows = p.n_parts = p.part = 0
+        return p
+
     def drain():
         torch.cuda.synchronize()
         for buf, want, what in pending:
-            assert_images_equal(buf.cpu().numpy(), want, f"seed {seed}: {what}")
+            assert_images_equal(buf.cpu().numpy()[:want.shape[0]], want, f"seed {seed}: {what}")
         pending.clear()
 
     try:
@@ -617,10 +632,10 @@ def test_random_call_sequences_keep_the_context_consistent(oracle, seed):
                 sd = with_camera(sd, gcam)
                 acc = None                                         # (the sums of another view are not this one's: the host resets, as Raytracer does)
             elif op == "render":
-                p = params()
+                p = partitioned(params())
                 assert_images_equal(ctx.render(p), oracle.render(sd, p), f"seed {seed} step {step}: blocking render")
             elif op == "device":
-                p = params()
+                p = partitioned(params())
                 buf = torch.full((h, w, 4), 0xAB, dtype=torch.uint8, device="cuda")
                 torch.cuda.current_stream().synchronize()          # the fill must land before a side stream's kernel writes the buffer
                 st = streams[int(rng.integers(len(streams)))]
