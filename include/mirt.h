@@ -353,6 +353,15 @@ const char* mirt_ctx_last_kernel(const MirtContext* ctx);
 
 /* Block until everything the context queued has finished. */
 int mirt_ctx_synchronize(MirtContext* ctx);
+/* Two streams of the context on DIFFERENT hardware queues, for hosts that keep two frames in flight -- a swap chain's double buffering:
+ * queue frame k on stream k & 1 into framebuffer k & 1 (mirt_ctx_render_device) and the head of frame k + 1 fills the GPU while the tail
+ * of frame k drains: 1080p, 2 spp 98.9 -> 83.9 us per frame; `Layer::set_data` at 800x600, 2 spp 12.8 -> 7.7 us.  index 0 is the context's
+ * own stream (what a NULL hip_stream means), index 1 a stream of the device's highest priority, created on first use -- HIP keeps
+ * hardware queues per priority, so the pair never shares one, which two streams of the caller's may (they then run one after the other).
+ * *out_hip_stream is a hipStream_t owned by the context: pass it as `hip_stream`, wait on it with hipStreamSynchronize or
+ * mirt_ctx_synchronize; it dies with the context.  Frames in flight must not share a framebuffer; mirt_ctx_accum_add calls stay ordered
+ * among themselves (one stream).  MIRT_ERR_BAD_ROWS for index > 1. */
+int mirt_ctx_frame_stream(MirtContext* ctx, uint32_t index, void** out_hip_stream);
 /* Kernel timing on (the default) or off.  ON: every launch carries a start and an end event (on the kernel dispatch itself) and
  * mirt_ctx_get_stats reports kernel times.  OFF: a launch carries no event unless the context itself must learn that it has finished
  * (launches that take work units from the dispenser, counting launches): mirt_ctx_get_stats then counts launches but reports 0 ms for

@@ -207,6 +207,7 @@ extern "C" {
     pub fn mirt_ctx_render_device(ctx: *mut MirtContext, params: *const MirtParams, d_out_rgba8: *mut c_void, out_len: usize, hip_stream: *mut c_void) -> c_int;
     pub fn mirt_ctx_synchronize(ctx: *mut MirtContext) -> c_int;
     pub fn mirt_ctx_get_stats(ctx: *mut MirtContext, out: *mut MirtStats) -> c_int;
+    pub fn mirt_ctx_frame_stream(ctx: *mut MirtContext, index: u32, out_hip_stream: *mut *mut c_void) -> c_int;
     pub fn mirt_ctx_set_timing(ctx: *mut MirtContext, enabled: c_int) -> c_int;
     pub fn mirt_ctx_last_kernel(ctx: *const MirtContext) -> *const c_char;
     pub fn mirt_ctx_accum_reset(ctx: *mut MirtContext, params: *const MirtParams) -> c_int;

@@ -59,7 +59,7 @@ def test_status_strings_match_header_enum():
 
 
 def test_version():
-    assert m.lib().mirt_version() == (0 << 16) | (4 << 8) | 0     # 0.4.0: mirt_grid_plan + MirtGridPlan, mirt_ctx_set_timing (0.3.0: MirtParams.frame_begin, MIRT_ERR_SPP_RANGE, MIRT_MAX_SPP_PER_CALL)
+    assert m.lib().mirt_version() == (0 << 16) | (4 << 8) | 0     # 0.4.0: mirt_grid_plan + MirtGridPlan, mirt_ctx_set_timing, mirt_ctx_frame_stream (0.3.0: MirtParams.frame_begin, MIRT_ERR_SPP_RANGE, MIRT_MAX_SPP_PER_CALL)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

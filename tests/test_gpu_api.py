@@ -334,6 +334,39 @@ def test_accumulation_on_the_default_stream_then_resolve(gpu_ctx, oracle):
         assert np.array_equal(sums, oracle.render_pt_sums(sd, want))
 
 
+def test_frame_streams_keep_two_frames_in_flight(oracle):
+    """mirt_ctx_frame_stream: the context's two streams on different hardware queues.  Frames alternate between them and between two
+    framebuffers -- dispensed, one-unit-per-wave and pooled launches, timing on and off -- and every frame checked is the oracle's;
+    mirt_ctx_synchronize waits for both streams; the handles are stable, differ, and index 2 is refused."""
+    import torch
+    w, h = 320, 180
+    sd = scene_data("three_spheres", w, h)
+    ctx = m.Context(0)
+    try:
+        ctx.set_scene(sd)
+        s0, s1 = ctx.frame_stream(0), ctx.frame_stream(1)
+        assert s0 != s1 and s0 != 0 and s1 != 0 and (ctx.frame_stream(0), ctx.frame_stream(1)) == (s0, s1)
+        assert _abi.STATUS[_status(lambda: ctx.frame_stream(2))] == "MIRT_ERR_BAD_ROWS"
+        bufs = [torch.empty((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for timing in (True, False):
+            ctx.set_timing(timing)
+            for spp, flags in ((2, 0), (8, 0), (24, 0), (48, m.MIRT_FLAG_KERNEL_POOL)):
+                ps = [m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, seed=k, flags=flags) for k in range(2)]
+                want = [oracle.render(sd, p) for p in ps]
+                for b in bufs:
+                    b.fill_(0xAB)
+                torch.cuda.synchronize()
+                ctx.stats()
+                for i in range(40):
+                    ctx.render_device(ps[i % 2], bufs[i % 2].data_ptr(), bufs[0].numel(), (s0, s1)[i % 2])
+                ctx.synchronize()                              # no torch synchronisation: the context waits for both of its streams
+                for k in range(2):
+                    assert not _frames_differ(bufs[k].cpu().numpy(), want[k]), (timing, spp, k, _frames_differ(bufs[k].cpu().numpy(), want[k]))
+                assert ctx.stats()["launches"] == 40
+    finally:
+        ctx.close()
+
+
 def test_set_scene_is_failure_atomic(gpu_ctx):
     """A set_scene that fails (here: rejected up front) or half-fails leaves the context without a scene
     rather than with stale tables: the next render must answer MIRT_ERR_NO_SCENE or render the OLD scene whole."""

@@ -160,6 +160,7 @@ SYMBOLS = {
     "mirt_ctx_accum_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mirt_ctx_selftest_math": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "mirt_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mirt_ctx_frame_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "mirt_render": (C.c_int, [_P(MirtScene), _P(MirtParams), C.c_int, C.c_void_p, C.c_size_t]),
     "mirt_rgba8_to_rgb8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "mirt_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_uint32), _P(C.c_uint32)]),

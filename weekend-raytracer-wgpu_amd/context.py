@@ -162,6 +162,13 @@ class Context:
     def synchronize(self) -> None:
         check(lib().mirt_ctx_synchronize(self._h))
 
+    def frame_stream(self, index: int) -> int:
+        """hipStream_t handle (an int for the `stream` arguments here) of the context's frame stream 0 or 1: two streams on different
+        hardware queues for hosts that keep two frames in flight (mirt_ctx_frame_stream)."""
+        h = C.c_void_p()
+        check(lib().mirt_ctx_frame_stream(self._h, index, C.byref(h)))
+        return int(h.value)
+
     def set_timing(self, enabled: bool) -> None:
         """Kernel timing on (default: every launch carries an event pair, `stats()` reports kernel times) or off (launches carry no
         event unless the context needs one: the reference's interactive frames queue back to back 30 % faster)."""
