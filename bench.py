@@ -704,8 +704,12 @@ def main(argv=None) -> int:
     # N > 1: the gather of frame i overlaps the render of frame i+1 (double-buffered parts, async collective);
     # every frame is complete on rank 0 before the timed region ends (flush).  MIRT_BENCH_PIPELINE=0: one frame at a time.
     pipelined = multi and os.environ.get("MIRT_BENCH_PIPELINE", "1") != "0"
+    # ... and consecutive frames RENDER on the context's two frame streams (mirt_ctx_frame_stream: different hardware queues): a rank's
+    # share of a frame is a short launch whose ramp and tail then overlap its neighbours' (one rank's share of config 3 at N = 8 on one
+    # GPU: 89.5 -> 95.4 % of the ideal eighth; profiles/r04_part_overlap.txt).  MIRT_BENCH_FRAMES_IN_FLIGHT=1: one stream.
+    in_flight = 2 if pipelined and not dry and os.environ.get("MIRT_BENCH_FRAMES_IN_FLIGHT", "2") != "1" else 1
     frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined, device=device,
-                                   _rehearse_single_rank=multi and world == 1)
+                                   _rehearse_single_rank=multi and world == 1, frames_in_flight=in_flight)
 
     def gather_now():
         """ONE gather of the current part buffers to rank 0 (the rehearsal's one-rank group included)."""
@@ -776,6 +780,7 @@ def main(argv=None) -> int:
     elapsed = time.perf_counter() - t0
     st = ctx.stats()                                    # HIP-event time of the K kernels of the timed region
     kernel_ms = st["kernel_ms_total"] / max(1, st["launches"])
+    step_ms_this_rank = elapsed / max(1, args.steps) * 1e3
     red_dev = torch.device("cpu") if dry else torch.device("cuda")
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -791,7 +796,13 @@ def main(argv=None) -> int:
         kernel_ms_per_rank = [round(kernel_ms, 4)]
     partition = ("whole frame" if not multi else
                  f"{args.tile_rows}-row tiles interleaved over {world} ranks + 1 gather per frame"
-                 + (" (overlapping the next frame's render)" if pipelined else ""))
+                 + (" (overlapping the next frame's render)" if pipelined else "")
+                 + ("; consecutive frames render on the context's two frame streams (two frames in flight)" if in_flight == 2 else ""))
+    # Two frames in flight: a launch's HIP-event duration includes the time it shares the GPU with its neighbour, so the roofline of such a
+    # line is priced on WALL time per step instead -- this rank's for `achieved`, the job's (max over ranks) for `achieved_whole_job`; both
+    # contain whatever the rank waits for (the gather), i.e. they are lower bounds of what the kernel does.
+    roof_ms = step_ms_this_rank if in_flight == 2 else kernel_ms
+    roof_ms_job = elapsed / max(1, args.steps) * 1e3 if in_flight == 2 else kernel_ms_max
     total_samples = w * h * spp
 
     # N > 1: one gather + de-interleave on its own, after the clock has stopped (the timed region overlaps it with the next
@@ -861,7 +872,7 @@ def main(argv=None) -> int:
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
         traffic = profiled_traffic(kernel_name, cfg["workload"]) if not multi else None
-        achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
+        achieved_tflops = flops / (roof_ms * 1e-3) / 1e12
         out_bytes = frame.rows * w * 4
         algo_bytes = algorithmic_bytes(sd, cfg["mode"], out_bytes)
         lane_slots = 64 * work["wave_iterations"]
@@ -894,8 +905,12 @@ def main(argv=None) -> int:
                 "traffic_source": (f"profiles/{traffic[1]} (rocprofv3 PMC, N=1 run of this workload)" if traffic else None),
                 "valu_busy_pct_profiled": (round(traffic[2], 1) if traffic and traffic[2] is not None else None),
                 "valu_lane_utilization_pct_profiled": (round(traffic[3], 1) if traffic and traffic[3] is not None else None),
-                "scope": "whole frame" if not multi else f"rank 0's share (its tiles: {frame.rows} of {h} rows); achieved_whole_job = all ranks' flops / slowest rank's kernel time",
-                "achieved_whole_job": round(flops_all / (kernel_ms_max * 1e-3) / 1e12, 3),
+                "scope": ("whole frame" if not multi else
+                          f"rank 0's share (its tiles: {frame.rows} of {h} rows); achieved_whole_job = all ranks' flops / slowest rank's kernel time" if in_flight != 2 else
+                          f"rank 0's share (its tiles: {frame.rows} of {h} rows), two frames in flight: achieved = its flops per step / its WALL time per step "
+                          "(launches overlap, so their HIP-event durations -- kernel_ms_* below -- include shared time); achieved_whole_job = all ranks' flops / the job's wall time per step"),
+                "frames_in_flight": in_flight,
+                "achieved_whole_job": round(flops_all / (roof_ms_job * 1e-3) / 1e12, 3),
                 "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),

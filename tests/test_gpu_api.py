@@ -163,10 +163,11 @@ def test_collective_path_on_a_single_rank_rccl_group(gpu_ctx):
         w, h, spp = 160, 90, 16
         gpu_ctx.set_scene(scene_data("three_spheres", w, h))
         side = torch.cuda.Stream()
-        for pipelined, stream in ((False, None), (True, None), (False, side), (True, side)):   # default stream, then a side stream
+        # default stream, then a side stream; last: two frames in flight (renders on the context's frame streams, what bench.py's N > 1 runs do)
+        for pipelined, stream, in_flight in ((False, None, 1), (True, None, 1), (False, side, 1), (True, side, 1), (True, None, 2), (True, side, 2)):
             with torch.cuda.stream(stream):
                 base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
-                fr = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1, pipelined=pipelined, _rehearse_single_rank=True)
+                fr = m.multi_gpu.TiledFrame(gpu_ctx, base, 0, 1, pipelined=pipelined, _rehearse_single_rank=True, frames_in_flight=in_flight)
                 for seed in range(5):
                     fr.params.seed = seed
                     fr.step()
@@ -176,7 +177,7 @@ def test_collective_path_on_a_single_rank_rccl_group(gpu_ctx):
                 dist.barrier()
             torch.cuda.synchronize()
             want = gpu_ctx.render(m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8, seed=4))
-            assert_images_equal(fr.frame.cpu().numpy(), want, f"last of five frames, pipelined={pipelined}, side stream={stream is not None}")
+            assert_images_equal(fr.frame.cpu().numpy(), want, f"last of five frames, pipelined={pipelined}, side stream={stream is not None}, {in_flight} in flight")
             assert float(t.item()) == 2.5
     finally:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ buffers, the asynchronous gather of frame k travelling while frame k+1 renders, 
 Every frame carries a different seed, so a frame assembled from the wrong buffer cannot pass.  Run by tests/test_gpu_multi.py as a
 child process (it spawns its ranks before it has touched the GPU); prints one line, "N ranks ok: ...", on success.
 
-    python tests/two_ranks_one_gpu.py [frames] [ranks]"""
+    python tests/two_ranks_one_gpu.py [frames] [ranks] [frames in flight: 1 or 2]"""
 import os
 import socket
 import sys
@@ -15,7 +15,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def worker(rank: int, world: int, port: int, frames: int) -> None:
+def worker(rank: int, world: int, port: int, frames: int, in_flight: int) -> None:
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -32,7 +32,7 @@ def worker(rank: int, world: int, port: int, frames: int) -> None:
     ctx.set_scene(sd)
     base = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=8)
     torch.cuda.set_stream(torch.cuda.Stream())
-    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=4, pipelined=True)
+    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=4, pipelined=True, frames_in_flight=in_flight)
     got = []
     for k in range(frames):
         frame.params.seed = 100 + k                # the frame index travels in the seed: frames differ
@@ -54,7 +54,7 @@ def worker(rank: int, world: int, port: int, frames: int) -> None:
         alone.close()
         assert len(got) == frames and not bad, f"frames {bad} of {frames} differ from the single-rank render"
         assert any(not np.array_equal(got[0], g) for g in got[1:]), "the frames must differ from each other"
-        print(f"{world} ranks ok: {frames} pipelined frames of {w}x{h}x{spp} spp, each equal to the single-rank render", flush=True)
+        print(f"{world} ranks ok: {frames} pipelined frames of {w}x{h}x{spp} spp ({in_flight} in flight), each equal to the single-rank render", flush=True)
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -67,4 +67,5 @@ if __name__ == "__main__":
         port = s.getsockname()[1]
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # at most 4: the GPU box allows 6 processes on its card
-    mp.spawn(worker, args=(world, port, frames), nprocs=world, join=True)
+    in_flight = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # 2: consecutive frames render on the context's two frame streams
+    mp.spawn(worker, args=(world, port, frames, in_flight), nprocs=world, join=True)

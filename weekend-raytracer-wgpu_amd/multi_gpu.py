@@ -71,10 +71,16 @@ class TiledFrame:
 
     `pipelined=True` (world > 1) double-buffers the part buffers and issues the gather with `async_op=True`:
     the gather of frame i travels while frame i+1 renders, and rank 0 de-interleaves frame i after that.  Ranks
-    then no longer meet once per frame; `flush()` completes the frames still in flight."""
+    then no longer meet once per frame; `flush()` completes the frames still in flight.
+
+    `frames_in_flight=2` (pipelined, on a GPU) also RENDERS consecutive frames on the context's two frame streams
+    (`mirt_ctx_frame_stream`: different hardware queues): a rank's share of a frame is a short launch -- 3 ms of config 3 at
+    N = 8 -- whose ramp and tail then overlap the neighbouring frames' (one rank's share on one GPU: 89.5 -> 95.4 % of the ideal
+    1/8 of the whole frame's time).  Buffer b's render, gather and de-interleave all live on frame stream b; an
+    event chain keeps rank 0's de-interleaves in frame order."""
 
     def __init__(self, ctx: Context, base: _abi.MirtParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS,
-                 pipelined: bool = False, _rehearse_single_rank: bool = False, device=None):
+                 pipelined: bool = False, _rehearse_single_rank: bool = False, device=None, frames_in_flight: int = 1):
         """`ctx` renders (`render_device`) and de-interleaves (`deinterleave_device`) into the buffers allocated
         here.  `device` defaults to the context's GPU; the CPU rehearsals of the N > 1 path (gloo; tests and
         `bench.py --dry-run`) pass torch.device("cpu") together with a stand-in context."""
@@ -99,6 +105,11 @@ class TiledFrame:
         self.parts = self.parts_bufs[0] if self.parts_bufs else None
         self._pending = [None] * n_buf
         self._k = 0
+        # two frames in flight: torch views of the context's frame streams (the collective and its wait() act on torch's CURRENT stream)
+        self._frame_streams = None
+        self._assembled = None                            # event after rank 0's latest de-interleave
+        if frames_in_flight == 2 and self.pipelined and dev.type == "cuda":
+            self._frame_streams = [torch.cuda.ExternalStream(ctx.frame_stream(i), device=dev) for i in range(2)]
 
     def _assemble(self, parts, stream):
         if self._rehearse:
@@ -117,6 +128,38 @@ class TiledFrame:
         self._pending[b] = None
         if self.rank == 0:
             self._assemble(self.parts_bufs[b], stream)
+
+    def _retire_on_frame_stream(self, b: int) -> None:
+        """Two frames in flight: the same on frame stream b, after the previous frame's de-interleave (they write one frame buffer)."""
+        import torch
+        fs = self._frame_streams[b]
+        with torch.cuda.stream(fs):
+            self._pending[b].wait()
+            self._pending[b] = None
+            if self.rank == 0:
+                if self._assembled is not None:
+                    fs.wait_event(self._assembled)
+                self._assemble(self.parts_bufs[b], fs.cuda_stream)
+                self._assembled = torch.cuda.Event()
+                self._assembled.record(fs)
+
+    def _step_two_in_flight(self):
+        import torch
+        import torch.distributed as dist
+        b = self._k & 1
+        fs = self._frame_streams[b]
+        if self._k < 2:                                    # the caller's stream may still be filling what this frame reads or writes
+            fs.wait_stream(torch.cuda.current_stream())
+        if self._pending[b] is not None:                   # frame k-2 (normally retired one step ago): its gather read locals[b]
+            self._retire_on_frame_stream(b)
+        with torch.cuda.stream(fs):
+            self.ctx.render_device(self.params, self.locals[b].data_ptr(), self.rows * self.base.width * 4, fs.cuda_stream)
+            gather_list = list(self.parts_bufs[b].unbind(0)) if self.rank == 0 else None
+            self._pending[b] = dist.gather(self.locals[b], gather_list, dst=0, async_op=True)
+        if self._pending[b ^ 1] is not None:               # frame k-1: its gather had a whole render to complete
+            self._retire_on_frame_stream(b ^ 1)
+        self._k += 1
+        return self.frame
 
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble.  Returns the frame tensor on rank 0
@@ -137,6 +180,8 @@ class TiledFrame:
             if self.rank == 0:
                 self._assemble(parts, stream)
             return self.frame
+        if self._frame_streams is not None:
+            return self._step_two_in_flight()
         b = self._k & 1
         if self._pending[b] is not None:                   # frame k-2 (normally retired one step ago)
             self._retire(b, stream)
@@ -154,5 +199,12 @@ class TiledFrame:
         if self.pipelined:
             for b in ((self._k & 1), (self._k & 1) ^ 1):
                 if self._pending[b] is not None:
-                    self._retire(b, stream)
+                    if self._frame_streams is not None:
+                        self._retire_on_frame_stream(b)
+                    else:
+                        self._retire(b, stream)
+            if self._frame_streams is not None:            # what follows on the caller's stream sees the finished frame
+                import torch
+                for fs in self._frame_streams:
+                    torch.cuda.current_stream().wait_stream(fs)
         return self.frame
