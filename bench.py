@@ -129,8 +129,8 @@ def kernel_uses_grid(name: str) -> bool:
     if "<" not in name:
         return False
     targs = name[name.index("<") + 1:name.rindex(">")].split(",")
-    if name.startswith("render_pt_pool_kernel"):
-        return targs[-1] == "true"
+    if name.startswith("render_pt_pool_kernel"):          # <threads, slots, min waves, COUNT, HOSEK, NQ, GRID, FLATY>
+        return len(targs) > 6 and targs[6] == "true"
     if name.startswith("render_pt_strip_kernel"):
         return targs[2] == "true"
     return False

@@ -50,6 +50,9 @@ def test_parity_and_grid_flop_formulas():
 def test_kernel_name_parsing():
     assert bench.kernel_uses_grid("render_pt_pool_kernel<256,112,3,false,false,5,true>")
     assert not bench.kernel_uses_grid("render_pt_pool_kernel<256,112,6,false,false,3,false>")
+    assert bench.kernel_uses_grid("render_pt_pool_kernel<1024,152,4,false,false,1,true,true>")             # round 4: + FLATY (a grid one cell high)
+    assert bench.kernel_uses_grid("render_pt_pool_kernel<1024,152,4,false,false,1,true,false>")
+    assert not bench.kernel_uses_grid("render_pt_pool_kernel<256,112,6,false,false,3,false,false>")
     assert bench.kernel_uses_grid("render_pt_strip_kernel<false,false,true,false>")
     assert not bench.kernel_uses_grid("render_pt_strip_kernel<false,false,false,true>")
     assert not bench.kernel_uses_grid("render_parity_kernel<false,false>") and not bench.kernel_uses_grid("")

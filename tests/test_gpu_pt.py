@@ -535,7 +535,7 @@ def test_camera_ray_candidate_lists(gpu_ctx, oracle, case):
     want = oracle.render(sd, m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=m.MIRT_FLAG_COUNT_WORK))
     want_counts = oracle.stats()
     got = gpu_ctx.render(p)
-    assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and gpu_ctx.last_kernel().endswith(",true>")
+    assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and ",1,true," in gpu_ctx.last_kernel()
     assert_images_equal(got, want, case)
     pc = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=5, flags=m.MIRT_FLAG_KERNEL_POOL | m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)
     assert_images_equal(gpu_ctx.render(pc), want, case + " (counting build)")
@@ -733,7 +733,81 @@ def test_grid_builds_on_random_soups(gpu_ctx, oracle, seed):
         p.flags = LINEAR | fl
         assert_images_equal(gpu_ctx.render(p), want, f"seed {seed}: {n} spheres, flags {fl}, {gpu_ctx.last_kernel()}")
         if fl == m.MIRT_FLAG_KERNEL_POOL:
-            assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and gpu_ctx.last_kernel().endswith(",1,true>")
+            assert gpu_ctx.last_kernel().startswith("render_pt_pool_kernel<1024,") and ",1,true," in gpu_ctx.last_kernel()
+
+
+def _ground_plane_soup(rng, n, spread, r_lo, r_hi, n_big=2, lattice=False):
+    """Spheres resting on the ground sphere (RTIOW's layout): with radii this close the uniform grid is ONE cell high."""
+    T = m.Texture
+    mats = [m.Material.Lambertian(T.new_from_color(rng.random(3))), m.Material.Metal(T.new_from_color(0.5 + 0.5 * rng.random(3)), 0.3),
+            m.Material.Dielectric(1.5), m.Material.Checkerboard(even=T.new_from_color((0.2, 0.3, 0.1)), odd=T.new_from_color((0.9, 0.9, 0.9)))]
+    gm, tex = m.flatten_materials(mats)
+    spheres = [m.Sphere.new((0.0, -1000.0, 0.0), 1000.0, 3).to_c()]
+    for _ in range(n_big):
+        spheres.append(m.Sphere.new((float(rng.normal() * spread * 0.3), 1.0, float(rng.normal() * spread * 0.3)), 1.0, int(rng.integers(0, 3))).to_c())
+    k = int(np.ceil(np.sqrt(n)))
+    for i in range(n):
+        r = float(rng.uniform(r_lo, r_hi))
+        if lattice:             # centres ON a lattice of 0.5 (binary fractions): rays along the axes meet cell faces and sphere poles exactly
+            x, z = 0.5 * (i % k - k // 2), 0.5 * (i // k - k // 2)
+            r = 0.125
+        else:
+            x, z = float(rng.normal() * spread), float(rng.normal() * spread)
+        spheres.append(m.Sphere.new((x, r, z), r, int(rng.integers(0, 4))).to_c())
+    return spheres, gm, tex
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ0, _FUZZ0 + int(os.environ.get("MIRT_FLAT_GRID_FUZZ_SEEDS", "8"))))
+def test_flat_grids_walk_in_two_dimensions(oracle, seed, monkeypatch):
+    """A grid ONE cell high (spheres on a ground plane: RTIOW, BASELINE configs[4]) is walked in two dimensions by the pooled kernel
+    (csrc grid_walk<COUNT, FLATY>; the y slab ends the walk through the clip's tmax).  Random ground-plane soups under random cameras
+    -- above, inside the slab, grazing, with and without a lens; every other seed on a lattice that puts cell faces, sphere poles and
+    ray origins on binary fractions -- must give the oracle's flat-scan image exactly, and byte for byte the frame of the
+    three-dimensional walk (MIRT_GRID_FLAT_Y=0)."""
+    rng = np.random.default_rng(15000 + seed)
+    lattice = seed % 2 == 1
+    n = int(rng.integers(40, 600))
+    spheres, gm, tex = _ground_plane_soup(rng, n, float(rng.uniform(1.0, 6.0)), 0.16, 0.2, n_big=int(rng.integers(0, 4)), lattice=lattice)
+    w, h, spp = 96, 54, int(rng.choice([32, 48, 100]))
+    kind = seed % 4
+    if kind == 0:
+        cam = simple_camera(w, h, eye=(float(rng.normal() * 3), float(rng.uniform(0.5, 4.0)), float(rng.uniform(4, 10))),
+                            direction=(float(rng.normal() * 0.3), -0.3, -1.0), vfov=float(rng.uniform(25, 70)), aperture=float(rng.choice([0.0, 0.2])), focus=8.0)
+    elif kind == 1:               # inside the slab, looking along -z on a cell face (x = 0 exactly; the lattice's centres are multiples of 0.5)
+        cam = simple_camera(w, h, eye=(0.0, 0.125, 6.0), direction=(0.0, 0.0, -1.0), vfov=40.0, aperture=0.0, focus=6.0)
+    elif kind == 2:               # grazing: just above the slab, almost horizontal
+        cam = simple_camera(w, h, eye=(float(rng.normal()), 0.45, 9.0), direction=(0.05, -0.02, -1.0), vfov=30.0, aperture=0.0, focus=9.0)
+    else:                         # from straight above, and a wide lens
+        cam = simple_camera(w, h, eye=(0.25, 12.0, 0.25), direction=(0.0, -1.0, -1e-3), vfov=50.0, aperture=0.5, focus=12.0)
+    sd = m.SceneData(cam, spheres, gm, tex)
+    p = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=int(rng.integers(2, 9)), flags=LINEAR | m.MIRT_FLAG_KERNEL_POOL)
+    want = oracle.render(sd, p)
+    flat = m.Context(0)
+    monkeypatch.setenv("MIRT_GRID_FLAT_Y", "0")
+    cubic = m.Context(0)                                       # tuning knobs are read once, in mirt_ctx_create
+    monkeypatch.delenv("MIRT_GRID_FLAT_Y")
+    try:
+        flat.set_scene(sd)
+        cubic.set_scene(sd)
+        got = flat.render(p)
+        assert flat.last_kernel().startswith("render_pt_pool_kernel<1024,") and flat.last_kernel().endswith(",1,true,true>"), flat.last_kernel()
+        assert_images_equal(got, want, f"seed {seed}: {n} spheres on the ground, camera kind {kind}, lattice {lattice}, {flat.last_kernel()}")
+        got3 = cubic.render(p)
+        assert cubic.last_kernel().endswith(",1,true,false>"), cubic.last_kernel()
+        assert np.array_equal(got3, got)
+        pc = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=p.num_bounces, flags=LINEAR | m.MIRT_FLAG_KERNEL_POOL | m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)
+        assert_images_equal(flat.render(pc), want, "counting build of the two-dimensional walk")
+        assert flat.last_kernel().endswith(",1,true,true>") and ",true,false,1," in flat.last_kernel(), flat.last_kernel()
+        st2, _ = flat.stats(), cubic.render(pc)
+        st3 = cubic.stats()
+        for k in ("rays", "hits", "sky_misses", "scatter", "sphere_tests"):      # same cells, same tests (an exact tie of a z crossing with the slab's end apart)
+            if k == "sphere_tests":
+                assert abs(st2[k] - st3[k]) <= 1e-4 * st3[k], (k, st2[k], st3[k])
+            else:
+                assert st2[k] == st3[k], (k, st2[k], st3[k])
+    finally:
+        flat.close()
+        cubic.close()
 
 
 def test_default_kernel_choice_follows_the_measured_crossovers(gpu_ctx):

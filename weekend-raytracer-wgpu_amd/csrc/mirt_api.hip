@@ -243,6 +243,7 @@ struct Tuning {
     int      stream = -1;             // MIRT_STREAM=0/1: lane-per-pixel launches in flat scenes never / always run the streaming build (A/B runs)
     int      px_groups = -1;          // MIRT_PX_GROUPS=0: lane-per-pixel units are always 64 pixels; 1 / 2 / 3: force 1 / 2 / 4 sample groups (A/B runs)
     int      strip_cand = -1;         // MIRT_STRIP_CAND=0: camera rays of grid builds take the grid like every other ray (A/B runs)
+    int      grid_flat_y = -1;        // MIRT_GRID_FLAT_Y=0: a grid one cell high is walked in three dimensions like any other (A/B runs, tests)
     bool     debug_slots = false;     // MIRT_DEBUG_SLOTS=1: every launch checks (synchronously) that its slot's dispenser words are zero
     uint32_t static_block = 0;        // MIRT_STATIC_BLOCK=64/128/256 (A/B runs): threads per block of the launches that run one unit per wave
     int      static_grid = -1;        // MIRT_STATIC_GRID=k (A/B runs): launches with one unit per wave run k x the resident blocks instead, units dealt round-robin
@@ -268,6 +269,7 @@ Tuning read_tuning()
     if (const char* e = std::getenv("MIRT_STREAM")) t.stream = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MIRT_PX_GROUPS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) t.px_groups = v; }
     if (const char* e = std::getenv("MIRT_STRIP_CAND")) t.strip_cand = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("MIRT_GRID_FLAT_Y")) t.grid_flat_y = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("MIRT_DEBUG_SLOTS")) t.debug_slots = e[0] == '1';
     if (const char* e = std::getenv("MIRT_STATIC_BLOCK")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) t.static_block = (uint32_t)v; }
     if (const char* e = std::getenv("MIRT_STATIC_GRID")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) t.static_grid = v; }
@@ -355,6 +357,7 @@ struct MirtContext {
     uint32_t grid_bytes = 0;
     bool     have_shade = false;             // d_shade holds this scene's records
     bool     grid_packable = false;          // the grid has at most kGridMaxCells cells: a parked walk's linear cell index fits 16 bits (always, as built)
+    bool     grid_flat_y = false;            // the grid is ONE cell high (dims[1] == 1: spheres on a ground plane): the pooled kernel walks it in two dimensions
     bool     fits_flat = true;               // spheres + materials fit the LDS budget (flat kernels usable)
     float*                d_texels = nullptr;
     MirtSkyState*         d_sky = nullptr;
@@ -716,9 +719,11 @@ int mirt_ctx_set_scene(MirtContext* c, const MirtScene* s)
     {
         c->grid_bytes = fits_grid ? (uint32_t)grid.size() : 0u;
         c->grid_packable = false;
+        c->grid_flat_y = false;
         if (fits_grid) {
             const mirt::GridHeader* gh = reinterpret_cast<const mirt::GridHeader*>(grid.data());
             c->grid_packable = gh->dims[0] * gh->dims[1] * gh->dims[2] <= mirt::kGridMaxCells;      // a parked walk keeps its linear cell index (16 bit)
+            c->grid_flat_y = gh->dims[1] == 1u && c->tuning.grid_flat_y != 0;
         }
         if (fits_grid) {
             if ((rc = ensure_capacity(&c->d_grid, &c->cap_grid, grid.size())) != MIRT_OK) return rc;
@@ -1008,6 +1013,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // in the strip kernel's lane-per-pixel units (64 pixels x spp) from 4 samples per pixel on -- measured on RTIOW 1080p: 2 spp +2 %
     // (selecting among 484 spheres costs more than 128 camera rays save), 8 spp -6 %
     a.strip_cand = (use_grid && tune.strip_cand != 0 && (pool_grid || p->spp >= 4u)) ? 1u : 0u;
+    a.grid_flat_y = (pool_grid && c->grid_flat_y) ? 1u : 0u;
     // (the strip kernel's grid build keeps a camera-ray candidate list per wave behind the blob: 4 waves x 48 bytes)
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 4u * 48u)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)

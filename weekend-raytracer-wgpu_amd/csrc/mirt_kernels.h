@@ -173,6 +173,7 @@ struct RenderArgs {
     uint32_t                grid_bytes;
     uint32_t                grid_pool_slots;   // pool kernel, grid build: slots per wave of the geometry chosen on the host
     uint32_t                strip_cand;        // pool kernel, grid build: 1 = camera rays scan their strip's candidate list (0: A/B runs)
+    uint32_t                grid_flat_y;       // pool kernel, grid build: 1 = the grid is ONE cell high (dims[1] == 1: spheres on a ground plane) -> the 2-D walk
     uint32_t*               work_counter;  // dynamic work dispenser: THIS launch's own word (one per event slot), preset before the launch
     unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;
@@ -235,7 +236,7 @@ uint32_t   pool_config_count();
 PoolConfig pool_config(uint32_t i, uint32_t nq);
 PoolConfig pool_config_grid(size_t lds_for_pools);   // grid build: slots by the LDS left beside scene + grid (slots = 0: none fits)
 hipError_t launch_pt_pool(const RenderArgs& a, uint32_t grid_blocks, uint32_t cfg, bool count, uint32_t nq, LaunchOn stream);
-// template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID>
+// template arguments of the pool kernel launch_pt_pool would start: <threads, slots, min waves, COUNT, HOSEK, NQ, GRID, FLATY>
 void       pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq, char* out, size_t out_len);
 uint32_t pool_scatter_queues(uint32_t n_routines, bool count);
 hipError_t launch_resolve(const unsigned long long* accum, uint32_t* out, uint64_t n_pixels, uint32_t n_samples,

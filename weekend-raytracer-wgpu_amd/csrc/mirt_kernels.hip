@@ -946,7 +946,7 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 // walk starts from; the cells visited may differ from the uncut walk's in the last bit of a crossing parameter,
 // which the conservative binning absorbs exactly as it absorbs the rounding of `tx += ddx` (see GridLds above).
 
-template <bool COUNT>
+template <bool COUNT, bool FLATY>
 MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool active, bool resume /* wave-uniform */, uint32_t budget,
                         float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane, Stamps& stamps)
 {
@@ -991,31 +991,36 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         walking = inside && (tmin <= tmax) && (tmin < closest);
         const f3 inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
         const f3 p0 = fma3(tmin, rd, ro);
-        cx = (int)((p0.x - org.x) * inv_cell.x); cy = (int)((p0.y - org.y) * inv_cell.y); cz = (int)((p0.z - org.z) * inv_cell.z);
+        cx = (int)((p0.x - org.x) * inv_cell.x); cz = (int)((p0.z - org.z) * inv_cell.z);
         cx = cx < 0 ? 0 : (cx >= dx ? dx - 1 : cx);
-        cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy);
         cz = cz < 0 ? 0 : (cz >= dz ? dz - 1 : cz);
+        if constexpr (FLATY) cy = 0;
+        else { cy = (int)((p0.y - org.y) * inv_cell.y); cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy); }
     } else {
         walking = active;
         // the parked LINEAR index taken apart: floor((n + 0.5) * (1 / d)) == n / d exactly for n, d <= 8192
-        const int nxy = dx * dy;
+        const int nxy = FLATY ? dx : dx * dy;
         cz = (int)(((float)cellp + 0.5f) * H.inv_dim_xy);
         const int rem = (int)cellp - cz * nxy;
-        cy = (int)(((float)rem + 0.5f) * H.inv_dim_x);
-        cx = rem - cy * dx;
+        if constexpr (FLATY) { cy = 0; cx = rem; }
+        else { cy = (int)(((float)rem + 0.5f) * H.inv_dim_x); cx = rem - cy * dx; }
     }
     const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
     // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
     float tx = rd.x != 0.0f ? (fma_((float)(cx + (sx > 0 ? 1 : 0)), cell.x, org.x) - ro.x) * inv_d.x : kHuge;
-    float ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
     float tz = rd.z != 0.0f ? (fma_((float)(cz + (sz > 0 ? 1 : 0)), cell.z, org.z) - ro.z) * inv_d.z : kHuge;
     const float ddx = rd.x != 0.0f ? abs_(cell.x * inv_d.x) : kHuge;
-    const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
     const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
+    float ty = kHuge, ddy = kHuge;
+    if constexpr (!FLATY) {
+        ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
+        ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
+    }
 
     // linear cell index, advanced with the walk (one multiply-add pair per WALK instead of per cell; the strides are selects)
-    uint32_t cidx = (uint32_t)((cz * dy + cy) * dx + cx);
-    const int stride_y = sy > 0 ? dx : -dx, stride_z = sz > 0 ? dx * dy : -(dx * dy);
+    uint32_t cidx = FLATY ? (uint32_t)(cz * dx + cx) : (uint32_t)((cz * dy + cy) * dx + cx);
+    const int nxy_ = FLATY ? dx : dx * dy;
+    const int stride_y = sy > 0 ? dx : -dx, stride_z = sz > 0 ? nxy_ : -nxy_;
     if (resume) stamps.mark(7); else stamps.mark(4);
     // (Letting an instalment run past its budget while most lanes are still walking was measured: the fuller instalments gain 1-2 %,
     //  but the loop header it needs -- ballot, population count and two compares instead of `it < budget && any` -- costs this loop 5 %.)
@@ -1029,14 +1034,29 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
         const uint32_t count = walking ? cw.x >> 16 : 0u;
         const uint2 cw_now = cw;
-        const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
-        const bool ax = (tx <= ty) & (tx <= tz);
-        const bool ay = !ax & (ty <= tz);
-        const bool az = !ax & !ay;
-        cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
-        cidx += (uint32_t)(ax ? sx : (ay ? stride_y : stride_z));
-        tx = ax ? tx + ddx : tx; ty = ay ? ty + ddy : ty; tz = az ? tz + ddz : tz;
-        const bool inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cy < (uint32_t)dy) & ((uint32_t)cz < (uint32_t)dz);
+        float t_exit;
+        bool inside_grid;
+        if constexpr (FLATY) {
+            // A grid ONE cell high (spheres on a ground plane: RTIOW): the walk is two-dimensional.  The y slab ends the walk through
+            // tmax -- the clip's far parameter on y is the very expression the 3-D walk's `ty` starts from (cy = 0, dims[1] = 1), so
+            // "y is the nearest crossing" there is "t_exit > tmax" here; on an exact tie of a z crossing with the slab's end this walk
+            // may test one more cell, which can only add candidates the flat scan tests as well.
+            t_exit = (tx < tz) ? tx : tz;
+            const bool ax = tx <= tz;
+            cx += ax ? sx : 0; cz += ax ? 0 : sz;
+            cidx += (uint32_t)(ax ? sx : stride_z);
+            tx = ax ? tx + ddx : tx; tz = ax ? tz : tz + ddz;
+            inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cz < (uint32_t)dz);
+        } else {
+            t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
+            const bool ax = (tx <= ty) & (tx <= tz);
+            const bool ay = !ax & (ty <= tz);
+            const bool az = !ax & !ay;
+            cx += ax ? sx : 0; cy += ay ? sy : 0; cz += az ? sz : 0;
+            cidx += (uint32_t)(ax ? sx : (ay ? stride_y : stride_z));
+            tx = ax ? tx + ddx : tx; ty = ay ? ty + ddy : ty; tz = az ? tz + ddz : tz;
+            inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cy < (uint32_t)dy) & ((uint32_t)cz < (uint32_t)dz);
+        }
         const bool may_go_on = walking & inside_grid & !(t_exit > tmax);
         if (it + 1 < budget) cw = G.cells[may_go_on ? cidx : 0u];                // in flight while the tests below run
         test_cell_entry<COUNT>(G, cw_now, count, ro, rd, a, inv_a, closest, best, work);
@@ -2011,35 +2031,42 @@ static hipError_t launch_pool_tile(const RenderArgs& a, uint32_t grid_blocks, bo
 
 // grid build of the default pool geometry: LDS (scene + grid + pools) bounds it to a few blocks per CU, so the
 // register budget is not the limit
-static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, LaunchOn stream)
+template <bool FLATY>
+static hipError_t launch_pool_grid_(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, LaunchOn stream)
 {
     const dim3 g(grid_blocks), b(kGridPoolThreads);
-    (void)nq;                                   // grid builds have ONE scatter queue (per-lane material switch)
     const uint32_t slots = a.grid_pool_slots;
 #ifdef MIRT_FAST_MATH
     if (count) return hipErrorInvalidValue;
 #else
     if (count) {                                // counting builds exist for the two largest geometries
         if (slots == kGridPoolSlotChoices[0])
-            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, true, 1, true>, g, b, a, stream)
-                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, false, 1, true>, g, b, a, stream);
+            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, true, 1, true, FLATY>, g, b, a, stream)
+                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], 1, true, false, 1, true, FLATY>, g, b, a, stream);
         if (slots == kGridPoolSlotChoices[1])
-            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, true, 1, true>, g, b, a, stream)
-                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, false, 1, true>, g, b, a, stream);
+            return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, true, 1, true, FLATY>, g, b, a, stream)
+                         : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], 1, true, false, 1, true, FLATY>, g, b, a, stream);
         return hipErrorInvalidValue;
     }
 #endif
     if (slots == kGridPoolSlotChoices[0])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, true, 1, true, FLATY>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[0], kGridPoolMinWaves, false, false, 1, true, FLATY>, g, b, a, stream);
     if (slots == kGridPoolSlotChoices[1])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, true, 1, true, FLATY>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[1], kGridPoolMinWaves, false, false, 1, true, FLATY>, g, b, a, stream);
     if (slots == kGridPoolSlotChoices[2])
-        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
-                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
-    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, true, 1, true>, g, b, a, stream)
-                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, false, 1, true>, g, b, a, stream);
+        return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, true, 1, true, FLATY>, g, b, a, stream)
+                     : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[2], kGridPoolMinWaves, false, false, 1, true, FLATY>, g, b, a, stream);
+    return hosek ? launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, true, 1, true, FLATY>, g, b, a, stream)
+                 : launch_with_lds(render_pt_pool_kernel<kGridPoolThreads, kGridPoolSlotChoices[3], kGridPoolMinWaves, false, false, 1, true, FLATY>, g, b, a, stream);
+}
+
+// grid builds have ONE scatter queue (per-lane material switch); FLATY = the grid is one cell high (RenderArgs.grid_flat_y)
+static hipError_t launch_pool_grid(const RenderArgs& a, uint32_t grid_blocks, bool count, bool hosek, uint32_t nq, LaunchOn stream)
+{
+    (void)nq;
+    return a.grid_flat_y ? launch_pool_grid_<true>(a, grid_blocks, count, hosek, stream) : launch_pool_grid_<false>(a, grid_blocks, count, hosek, stream);
 }
 
 // pool geometries {threads per block, slots per wave}; [0] is the default.  The kernel is held to 80 VGPRs
@@ -2139,7 +2166,8 @@ void pool_kernel_name(const RenderArgs& a, uint32_t cfg, bool count, uint32_t nq
             return;
         }
     }
-    snprintf(out, out_len, "render_pt_pool_kernel<%u,%u,%u,%s,%s,%u,%s>", threads, slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr]);
+    snprintf(out, out_len, "render_pt_pool_kernel<%u,%u,%u,%s,%s,%u,%s,%s>", threads, slots, minw, tf[count], tf[hosek], nq, tf[a.grid != nullptr],
+             tf[a.grid != nullptr && a.grid_flat_y != 0u]);
 }
 
 #ifndef MIRT_FAST_MATH
