@@ -18,8 +18,11 @@ def test_algorithmic_flops_formula():
 
 def test_profiled_traffic_lookup_matches_committed_summaries():
     # the headline kernel under the name mirt_ctx_last_kernel reports (this round's summaries) ...
-    new = bench.profiled_traffic("render_pt_pool_kernel<256,112,6,false,false,3,false>", bench.CONFIGS["3"]["workload"])
-    assert new is not None and new[1].startswith("r04_c3_pmc") and 8.29e6 <= new[0] <= 2 * 8.3e6      # the newest committed summary OF THIS WORKLOAD wins (not the 2-spp runs of the same kernel family)
+    new = bench.profiled_traffic("render_pt_pool_kernel<256,112,6,false,false,3,false,false>", bench.CONFIGS["3"]["workload"])
+    assert new is not None and new[1].startswith("r04b_c3_pmc") and 8.29e6 <= new[0] <= 2 * 8.3e6     # the newest committed summary OF THIS WORKLOAD wins (not the 2-spp runs of the same kernel family)
+    # (the pooled kernel gained an eighth template argument in round 4 -- FLATY, a grid one cell high -- so its profiles were taken again: r04b_*)
+    old = bench.profiled_traffic("render_pt_pool_kernel<256,112,6,false,false,3,false>", bench.CONFIGS["3"]["workload"])
+    assert old is not None and old[1].startswith("r04_c3_pmc")
     # ... and round 1's summaries under the name bench.py used then
     got = bench.profiled_traffic("render_pt_pool_kernel<256,112,false,false>")
     assert got is not None

@@ -795,6 +795,13 @@ def test_flat_grids_walk_in_two_dimensions(oracle, seed, monkeypatch):
         got3 = cubic.render(p)
         assert cubic.last_kernel().endswith(",1,true,false>"), cubic.last_kernel()
         assert np.array_equal(got3, got)
+        # the strip kernel's grid build (lane = pixel / lane = sample) takes the same two-dimensional walk behind a wave-uniform flag
+        for spp_s in (3, 16):
+            ps = m.make_params(w, h, spp_s, mode=m.MIRT_MODE_PT, num_bounces=p.num_bounces, flags=LINEAR | m.MIRT_FLAG_KERNEL_STRIP)
+            got_s = flat.render(ps)
+            assert flat.last_kernel().startswith("render_pt_strip_kernel<false,false,true,"), flat.last_kernel()
+            assert_images_equal(got_s, oracle.render(sd, ps), f"seed {seed}: strip kernel, {spp_s} spp, {flat.last_kernel()}")
+            assert np.array_equal(cubic.render(ps), got_s)
         pc = m.make_params(w, h, spp, mode=m.MIRT_MODE_PT, num_bounces=p.num_bounces, flags=LINEAR | m.MIRT_FLAG_KERNEL_POOL | m.MIRT_FLAG_COUNT_WORK | m.MIRT_FLAG_COUNT_GRID)
         assert_images_equal(flat.render(pc), want, "counting build of the two-dimensional walk")
         assert flat.last_kernel().endswith(",1,true,true>") and ",true,false,1," in flat.last_kernel(), flat.last_kernel()

@@ -1013,7 +1013,7 @@ static int launch_render(MirtContext* c, const MirtParams* p, uint32_t* d_out, h
     // in the strip kernel's lane-per-pixel units (64 pixels x spp) from 4 samples per pixel on -- measured on RTIOW 1080p: 2 spp +2 %
     // (selecting among 484 spheres costs more than 128 camera rays save), 8 spp -6 %
     a.strip_cand = (use_grid && tune.strip_cand != 0 && (pool_grid || p->spp >= 4u)) ? 1u : 0u;
-    a.grid_flat_y = (pool_grid && c->grid_flat_y) ? 1u : 0u;
+    a.grid_flat_y = (use_grid && c->grid_flat_y) ? 1u : 0u;
     // (the strip kernel's grid build keeps a camera-ray candidate list per wave behind the blob: 4 waves x 48 bytes)
     a.lds_bytes = use_grid ? (uint32_t)(scene_lds_g + a.grid_bytes + (pool ? pcu.lds_bytes : 4u * 48u)) : (uint32_t)(scene_lds + (pool ? pcu.lds_bytes : 0));
     if (!use_grid && !c->fits_flat)

@@ -173,7 +173,7 @@ struct RenderArgs {
     uint32_t                grid_bytes;
     uint32_t                grid_pool_slots;   // pool kernel, grid build: slots per wave of the geometry chosen on the host
     uint32_t                strip_cand;        // pool kernel, grid build: 1 = camera rays scan their strip's candidate list (0: A/B runs)
-    uint32_t                grid_flat_y;       // pool kernel, grid build: 1 = the grid is ONE cell high (dims[1] == 1: spheres on a ground plane) -> the 2-D walk
+    uint32_t                grid_flat_y;       // grid builds: 1 = the grid is ONE cell high (dims[1] == 1: spheres on a ground plane) -> the 2-D walk
     uint32_t*               work_counter;  // dynamic work dispenser: THIS launch's own word (one per event slot), preset before the launch
     unsigned long long*     accum;         // nullable: [pixels][3] exact fixed-point sums to ADD into instead of resolving
     uint64_t                n_texels;

@@ -859,7 +859,8 @@ MIRT_DEV void test_cell_items(const GridLds& G, uint32_t first, uint32_t count, 
     }
 }
 
-template <bool COUNT>
+// FLATY: the grid is one cell high -> the two-dimensional walk (see grid_walk below for the argument)
+template <bool COUNT, bool FLATY>
 MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool alive, float& closest_out, Work<COUNT>& work,
                               uint32_t lane)
 {
@@ -897,30 +898,40 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
     // a little slack on both ends: the walk below is clamped to the grid anyway
     bool walking = inside && (tmin <= tmax) && (tmin < closest);
     const f3 p0 = fma3(tmin, rd, ro);
-    int cx = (int)((p0.x - org.x) * inv_cell.x), cy = (int)((p0.y - org.y) * inv_cell.y), cz = (int)((p0.z - org.z) * inv_cell.z);
+    int cx = (int)((p0.x - org.x) * inv_cell.x), cy = 0, cz = (int)((p0.z - org.z) * inv_cell.z);
     cx = cx < 0 ? 0 : (cx >= dx ? dx - 1 : cx);
-    cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy);
     cz = cz < 0 ? 0 : (cz >= dz ? dz - 1 : cz);
+    if constexpr (!FLATY) { cy = (int)((p0.y - org.y) * inv_cell.y); cy = cy < 0 ? 0 : (cy >= dy ? dy - 1 : cy); }
     const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
     // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
     float tx = rd.x != 0.0f ? (fma_((float)(cx + (sx > 0 ? 1 : 0)), cell.x, org.x) - ro.x) * inv_d.x : kHuge;
-    float ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
     float tz = rd.z != 0.0f ? (fma_((float)(cz + (sz > 0 ? 1 : 0)), cell.z, org.z) - ro.z) * inv_d.z : kHuge;
     const float ddx = rd.x != 0.0f ? abs_(cell.x * inv_d.x) : kHuge;
-    const float ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
     const float ddz = rd.z != 0.0f ? abs_(cell.z * inv_d.z) : kHuge;
+    float ty = kHuge, ddy = kHuge;
+    if constexpr (!FLATY) {
+        ty = rd.y != 0.0f ? (fma_((float)(cy + (sy > 0 ? 1 : 0)), cell.y, org.y) - ro.y) * inv_d.y : kHuge;
+        ddy = rd.y != 0.0f ? abs_(cell.y * inv_d.y) : kHuge;
+    }
 
     while (ballot_(walking)) {
-        uint32_t first = 0, count = 0;
+        uint32_t count = 0;
         if constexpr (COUNT) { if (walking) work.add(kCntCells); if (lane == 0) work.add(kCntWaveCells); }
         {
-            const uint32_t c = walking ? (uint32_t)((cz * dy + cy) * dx + cx) : 0u;
+            const uint32_t c = walking ? (FLATY ? (uint32_t)(cz * dx + cx) : (uint32_t)((cz * dy + cy) * dx + cx)) : 0u;
             const uint2 cw = G.cells[c];
             count = walking ? cw.x >> 16 : 0u;
-            (void)first;
             test_cell_entry<COUNT>(G, cw, count, ro, rd, a, inv_a, closest, best, work);
         }
-        {   // one DDA step, branch-free (see grid_walk)
+        if constexpr (FLATY) {   // one DDA step in two dimensions: the slab's end stops the walk through tmax
+            const float t_exit = (tx < tz) ? tx : tz;
+            const bool stop = (closest <= t_exit) | (t_exit > tmax);
+            const bool ax = tx <= tz;
+            cx += ax ? sx : 0; cz += ax ? 0 : sz;
+            tx = ax ? tx + ddx : tx; tz = ax ? tz : tz + ddz;
+            const bool inside_grid = ((uint32_t)cx < (uint32_t)dx) & ((uint32_t)cz < (uint32_t)dz);
+            walking = walking & !stop & inside_grid;
+        } else {   // one DDA step, branch-free (see grid_walk)
             const float t_exit = (tx < ty) ? ((tx < tz) ? tx : tz) : ((ty < tz) ? ty : tz);
             const bool stop = (closest <= t_exit) | (t_exit > tmax);        // nearest hit is final, or the ray left the grid
             const bool ax = (tx <= ty) & (tx <= tz);
@@ -1486,7 +1497,9 @@ MIRT_DEV f3 path_radiance(const RenderArgs& A, const SceneLds& S, const GridLds&
                     test_sphere<COUNT>(G.recs[id], id, ro, rd, a, inv_a, alive, closest, best, work);
                 }
             } else {
-                best = nearest_hit_grid<COUNT>(S, G, ro, rd, alive, closest, work, lane);
+                // a grid ONE cell high (spheres on a ground plane) takes the two-dimensional walk; the flag is wave-uniform (host: dims[1] == 1)
+                best = A.grid_flat_y ? nearest_hit_grid<COUNT, true>(S, G, ro, rd, alive, closest, work, lane)
+                                     : nearest_hit_grid<COUNT, false>(S, G, ro, rd, alive, closest, work, lane);
             }
         } else best = nearest_hit<COUNT>(S, A.n_spheres, ro, rd, alive, closest, work);
         if (alive) {
