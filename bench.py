@@ -708,8 +708,49 @@ def main(argv=None) -> int:
     # share of a frame is a short launch whose ramp and tail then overlap its neighbours' (one rank's share of config 3 at N = 8 on one
     # GPU: 89.5 -> 95.4 % of the ideal eighth; profiles/r04_part_overlap.txt).  MIRT_BENCH_FRAMES_IN_FLIGHT=1: one stream.
     in_flight = 2 if pipelined and not dry and os.environ.get("MIRT_BENCH_FRAMES_IN_FLIGHT", "2") != "1" else 1
-    frame = m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pipelined, device=device,
-                                   _rehearse_single_rank=multi and world == 1, frames_in_flight=in_flight)
+    def make_frame(pl: bool, fl: int):
+        return m.multi_gpu.TiledFrame(ctx, base, rank, world, tile_rows=args.tile_rows, pipelined=pl, device=device,
+                                      _rehearse_single_rank=multi and world == 1, frames_in_flight=fl)
+
+    # N > 1: the overlapped schedules (asynchronous gather, two frames in flight on two streams) have only ever met RCCL with ONE rank
+    # (--rehearse-collectives), so a schedule must QUALIFY before it is timed: three untimed frames, then rank 0 compares the frame it
+    # assembled with its own single-GPU render of the whole frame (the pattern in a dry run), every rank learns the answer, and a schedule
+    # that does not reproduce the frame is replaced by the next more conservative one -- two frames in flight -> one stream, pipelined
+    # gather -> one frame at a time, blocking gather.  The line says which schedule ran and why (`schedule_check`).
+    schedule_check = []
+    if multi:
+        candidates = [(pipelined, in_flight)]
+        for c in ((pipelined, 1), (False, 1)):
+            if c not in candidates:
+                candidates.append(c)
+        fault = os.environ.get("MIRT_BENCH_FAULT_FIRST_SCHEDULE", "0") == "1"        # tests: the first candidate "fails"
+        frame = None
+        for k, (pl, fl) in enumerate(candidates):
+            frame = make_frame(pl, fl)
+            with stdout_to_stderr():                       # (the first collective of a communicator prints RCCL's banner)
+                for _ in range(3):
+                    frame.step()
+                frame.flush()
+                if not dry:
+                    torch.cuda.synchronize()
+            ok = True
+            if rank == 0:
+                if dry:
+                    import numpy as np
+                    ok = bool(np.array_equal(frame.frame.numpy(), pattern_rows(range(h), w)))
+                else:
+                    ok = bool(verify_whole_frame_self(m, torch, ctx, base, frame.frame, 0.0)["equal"])
+                if fault and k == 0:
+                    ok = False
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cpu") if dry else torch.device("cuda"))
+            dist.broadcast(flag, src=0)
+            ok = bool(int(flag.item()))
+            schedule_check.append({"pipelined_gather": bool(pl), "frames_in_flight": fl, "frame_equals_rank0_single_gpu_render": ok})
+            if ok:
+                break
+        pipelined, in_flight = candidates[len(schedule_check) - 1]
+    else:
+        frame = make_frame(pipelined, in_flight)
 
     def gather_now():
         """ONE gather of the current part buffers to rank 0 (the rehearsal's one-rank group included)."""
@@ -843,6 +884,7 @@ def main(argv=None) -> int:
             print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "frames_verified": ok, "verified_rows": rows, "verified_frame": "gathered on rank 0" if multi else "whole frame",
                               "gather_ms": gather_ms, "launches_rank0": st["launches"], "backend": "gloo" if multi else "none",
+                              "schedule_check": schedule_check,
                               "kernel_ms_per_rank": kernel_ms_per_rank,
                               "config": {"workload": f"DRY RUN ({w}x{h} pattern frame, no GPU, nothing measured)", "partition": partition}}),
                   flush=True)
@@ -940,6 +982,7 @@ def main(argv=None) -> int:
         if not multi and cfg["mode"] == "parity":
             result["parity_schedules"] = parity_schedules_line(m, torch, ctx, base, w, h)
         if multi:
+            result["schedule_check"] = schedule_check           # the schedules tried before the timed region, most overlapped first; the last one ran
             result["gather_ms"] = gather_ms
             result["gather_note"] = "one gather + de-interleave alone on rank 0 (no render), after the timed region; the timed steps overlap it with the next frame's render"
         cpu_rate = None

@@ -99,6 +99,28 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     assert d["gather_ms"] is not None and d["gather_ms"] > 0.0
 
 
+def test_an_overlapped_schedule_must_reproduce_the_frame_before_it_is_timed():
+    """N > 1: before the timed region every schedule runs three untimed frames and rank 0 compares what it assembled with its own
+    render of the whole frame (`schedule_check`); a schedule that fails is replaced by the next more conservative one -- here the first
+    candidate is made to fail (MIRT_BENCH_FAULT_FIRST_SCHEDULE=1): the pipelined gather gives way to one frame at a time, every rank
+    follows (the decision is broadcast), and the line verifies."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=dict(_bare_env(), MIRT_BENCH_FAULT_FIRST_SCHEDULE="1"), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    sc = d["schedule_check"]
+    assert [c["frame_equals_rank0_single_gpu_render"] for c in sc] == [False, True]
+    assert sc[0]["pipelined_gather"] and not sc[1]["pipelined_gather"] and sc[1]["frames_in_flight"] == 1
+    assert d["frames_verified"] and "overlapping the next frame's render" not in d["config"]["partition"]
+    # without the fault the first (most overlapped) schedule qualifies
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=_bare_env(), capture_output=True, text=True, timeout=600, cwd="/tmp")
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert len(d["schedule_check"]) == 1 and d["schedule_check"][0]["frame_equals_rank0_single_gpu_render"] and d["schedule_check"][0]["pipelined_gather"]
+    assert "overlapping the next frame's render" in d["config"]["partition"]
+
+
 def test_bench_rejects_a_world_size_mismatch():
     import os
     import subprocess

@@ -69,6 +69,9 @@ def test_the_n_rank_branches_run_over_rccl_on_one_gpu():
     assert "cpu_baseline" not in d and len(d["roofline"]["kernel_ms_per_rank"]) == 1
     assert all(v["against"] == "oracle" for v in d["verified_rows"])
     assert d["verified_whole_frame"]["equal"] is True and d["verified_whole_frame"]["rows"] == [0, 1080]
+    # the schedule qualified before it was timed: two frames in flight + the pipelined gather reproduce rank 0's own render
+    assert d["schedule_check"] == [{"pipelined_gather": True, "frames_in_flight": 2, "frame_equals_rank0_single_gpu_render": True}]
+    assert d["roofline"]["frames_in_flight"] == 2
 
 
 def test_the_8_gpu_headline_job_verifies_its_gathered_frame_without_the_oracle():
