@@ -759,6 +759,33 @@ struct GridLds {
     const float4*         recs;       // ... of every sphere, by sphere id (the cells' items are ids)
 };
 
+// What every step of the pooled kernel's grid build reads from the blob's header, and the always-tested spheres' records when there are
+// at most four of them (RTIOW: the ground and three heroes), held in REGISTERS for the whole kernel (round 4).  That build runs one
+// 1024-thread block per CU -- four waves per SIMD, whatever it does -- so the 128 VGPRs a wave may use are there for the taking: the walk
+// of round 4's block 9 used 96; the header's fields (11 registers: -1.2 %) and four records with their ids (-1.2 % more) fill the rest,
+// and a fresh step starts its sphere tests without waiting for six broadcast LDS reads (profiles/r04_c5_ab.txt block 13).
+struct GridConsts { f3 org, cell, inv_cell, hi; int dx, dy, dz; float inv_dim_x, inv_dim_xy;
+                    float4 bigr[4]; uint32_t bigid[4]; uint32_t n_big; };
+MIRT_DEV GridConsts load_grid_consts(const GridLds& G)
+{
+    const GridHeader& H = *G.h;
+    GridConsts c;
+    c.org = mk(H.org[0], H.org[1], H.org[2]);
+    c.cell = mk(H.cell[0], H.cell[1], H.cell[2]);
+    c.inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
+    c.dx = (int)H.dims[0]; c.dy = (int)H.dims[1]; c.dz = (int)H.dims[2];
+    c.hi = mk(fma_((float)c.dx, c.cell.x, c.org.x), fma_((float)c.dy, c.cell.y, c.org.y), fma_((float)c.dz, c.cell.z, c.org.z));
+    c.inv_dim_x = H.inv_dim_x; c.inv_dim_xy = H.inv_dim_xy;
+    c.n_big = __builtin_amdgcn_readfirstlane(H.n_big);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {                     // (entries past n_big: copies of entry 0 when there is one -- never tested)
+        const bool on = j < c.n_big;
+        c.bigr[j] = c.n_big ? G.big_recs[on ? j : 0u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        c.bigid[j] = c.n_big ? (uint32_t)G.big[on ? j : 0u] : 0u;
+    }
+    return c;
+}
+
 // one sphere test from its record s4 = {centre, r^2} (a copy of the first half of PreparedSphere i)
 template <bool COUNT>
 MIRT_DEV void test_sphere(const float4 s4, uint32_t i, f3 ro, f3 rd, float a, float inv_a, bool alive, float& closest, int& best,
@@ -959,14 +986,13 @@ MIRT_DEV int nearest_hit_grid(const SceneLds& S, const GridLds& G, f3 ro, f3 rd,
 
 template <bool COUNT, bool FLATY>
 MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool active, bool resume /* wave-uniform */, uint32_t budget,
-                        float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane, Stamps& stamps)
+                        float& closest, int& best, uint32_t& cellp, bool& walking, Work<COUNT>& work, uint32_t lane, Stamps& stamps,
+                        const GridConsts& GC)
 {
     const float a = dot(rd, rd);
     const float inv_a = rcp_(a);
-    const GridHeader& H = *G.h;
-    const f3 org = mk(H.org[0], H.org[1], H.org[2]);
-    const f3 cell = mk(H.cell[0], H.cell[1], H.cell[2]);
-    const int dx = (int)H.dims[0], dy = (int)H.dims[1], dz = (int)H.dims[2];
+    const f3 org = GC.org, cell = GC.cell;                 // the header's fields: registers (GridConsts), not LDS reads per step
+    const int dx = GC.dx, dy = GC.dy, dz = GC.dz;
     const float kHuge = 3.0e38f;
     // The crossing parameters only STEER the walk (which cells, when to stop); the hit itself is decided by the exact
     // sphere tests.  An error of a few ulp in them is absorbed by the conservative binning (cells are enlarged by
@@ -974,7 +1000,7 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
     // instruction, no range guard) is enough here; every build and the resumed instalments use the same one.
     const f3 inv_d = mk(rd.x != 0.0f ? __builtin_amdgcn_rcpf(rd.x) : kHuge, rd.y != 0.0f ? __builtin_amdgcn_rcpf(rd.y) : kHuge,
                         rd.z != 0.0f ? __builtin_amdgcn_rcpf(rd.z) : kHuge);
-    const f3 hi = mk(fma_((float)dx, cell.x, org.x), fma_((float)dy, cell.y, org.y), fma_((float)dz, cell.z, org.z));
+    const f3 hi = GC.hi;
     // the ray's parameter range inside the grid's box (both modes: tmax ends the walk)
     float tmin = 0.0f, tmax = kMaxT;
     bool inside = active;
@@ -997,10 +1023,15 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         best = -1;
         if (active) work.add(kCntRays);
         stamps.mark(4);                                       // (diagnosis builds) the clip against the grid's box
-        test_big_spheres<COUNT>(G, ro, rd, a, inv_a, active, closest, best, work);
+        if (GC.n_big <= 4u) {                                 // wave-uniform: the records live in registers
+            if (GC.n_big > 0u) test_sphere<COUNT>(GC.bigr[0], GC.bigid[0], ro, rd, a, inv_a, active, closest, best, work);
+            if (GC.n_big > 1u) test_sphere<COUNT>(GC.bigr[1], GC.bigid[1], ro, rd, a, inv_a, active, closest, best, work);
+            if (GC.n_big > 2u) test_sphere<COUNT>(GC.bigr[2], GC.bigid[2], ro, rd, a, inv_a, active, closest, best, work);
+            if (GC.n_big > 3u) test_sphere<COUNT>(GC.bigr[3], GC.bigid[3], ro, rd, a, inv_a, active, closest, best, work);
+        } else test_big_spheres<COUNT>(G, ro, rd, a, inv_a, active, closest, best, work);
         stamps.mark(3);
         walking = inside && (tmin <= tmax) && (tmin < closest);
-        const f3 inv_cell = mk(H.inv_cell[0], H.inv_cell[1], H.inv_cell[2]);
+        const f3 inv_cell = GC.inv_cell;
         const f3 p0 = fma3(tmin, rd, ro);
         cx = (int)((p0.x - org.x) * inv_cell.x); cz = (int)((p0.z - org.z) * inv_cell.z);
         cx = cx < 0 ? 0 : (cx >= dx ? dx - 1 : cx);
@@ -1011,10 +1042,10 @@ MIRT_DEV void grid_walk(const SceneLds& S, const GridLds& G, f3 ro, f3 rd, bool 
         walking = active;
         // the parked LINEAR index taken apart: floor((n + 0.5) * (1 / d)) == n / d exactly for n, d <= 8192
         const int nxy = FLATY ? dx : dx * dy;
-        cz = (int)(((float)cellp + 0.5f) * H.inv_dim_xy);
+        cz = (int)(((float)cellp + 0.5f) * GC.inv_dim_xy);
         const int rem = (int)cellp - cz * nxy;
         if constexpr (FLATY) { cy = 0; cx = rem; }
-        else { cy = (int)(((float)rem + 0.5f) * H.inv_dim_x); cx = rem - cy * dx; }
+        else { cy = (int)(((float)rem + 0.5f) * GC.inv_dim_x); cx = rem - cy * dx; }
     }
     const int sx = rd.x > 0.0f ? 1 : -1, sy = rd.y > 0.0f ? 1 : -1, sz = rd.z > 0.0f ? 1 : -1;
     // parameter at which the ray crosses the next cell boundary on each axis, and the per-cell increment
