@@ -599,6 +599,25 @@ MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A)
     return c;
 }
 
+// The pooled kernel's flat builds are held to 80 VGPRs (6 waves per SIMD) and use 70: nine of the idle ones keep hor / ver / llc for the whole
+// kernel, so a GEN step re-reads three rows of the camera from LDS instead of six (config 3: -0.4 %, 79 VGPRs; round 4).  Builds that would
+// spill for it (Hosek sky, texel tiles, counting) keep reading all six.
+struct CamHeld { f3 hor, ver, llc; };
+MIRT_DEV CamHeld hold_camera(const SceneLds& S) { return CamHeld{ mk(S.cam[4], S.cam[5], S.cam[6]), mk(S.cam[8], S.cam[9], S.cam[10]), mk(S.cam[20], S.cam[21], S.cam[22]) }; }
+MIRT_DEV CamRegs load_camera(const SceneLds& S, const RenderArgs& A, const CamHeld& H)
+{
+    CamRegs c;
+    c.eye = mk(S.cam[0], S.cam[1], S.cam[2]);
+    c.hor = H.hor; c.ver = H.ver; c.llc = H.llc;
+    c.cam_u = mk(S.cam[12], S.cam[13], S.cam[14]);
+    c.cam_v = mk(S.cam[16], S.cam[17], S.cam[18]);
+    c.lens_radius = S.cam[19];
+    c.pinhole = __builtin_amdgcn_readfirstlane(bits(S.cam[23])) != 0u;
+    c.inv_w = 1.0f / (float)A.width;
+    c.inv_h = 1.0f / (float)A.height;
+    return c;
+}
+
 // initRng (wgsl:498-502, frame = sample + 1) + samplePixel (wgsl:114-117) + cameraMakeRay (wgsl:456-478)
 // RESEED = false continues the caller's stream: the reference's samplePixel loop draws all samples of one frame from
 // the stream initRng seeded once for that frame (MirtParams.frame_spp > 0; lane-per-pixel schedule only).
