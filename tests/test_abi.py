@@ -113,6 +113,9 @@ def test_grid_plan_of_the_rtiow_scene():
     g = _grid_plan([s.to_c() for s in scene.spheres])
     assert g.cell_factor == 2.5 and g.n_big == 4 and g.pool_slots == 152            # ground + the three r = 1 spheres stay outside the grid
     assert 0 < g.blob_bytes < 26 * 1024 and g.n_cells <= 4096 and 0 < g.n_entries < 65536         # 24 640 B: two u32 per cell since round 4
+    # 45 x 1 x 45 cells of 0.5: the small spheres rest on the ground (y in [0, 0.4]), so the grid is ONE cell high -- what the kernels'
+    # two-dimensional walk (grid_walk<COUNT, FLATY>, RenderArgs.grid_flat_y) is for; a second layer would be 4 050 cells
+    assert g.n_cells == 45 * 45
     assert _grid_plan([s.to_c() for s in scene.spheres[:20]]).cell_factor == 0.0      # fewer than 32 spheres: no grid
 
 
